@@ -1,0 +1,127 @@
+/*
+ * moe_gfx950.h -- C ABI of libmoe_gfx950.so: the MI355X (gfx950) kernels behind the
+ * drop-in replacement of MoE-LLaVA's sparse MoE FFN block (deepspeed.moe.layer.MoE).
+ *
+ * Boundary rules:
+ *   - plain pointers and sizes only; every buffer (inputs, outputs, workspace) is
+ *     owned by the caller and lives in device memory of the current HIP device;
+ *   - the library never allocates, frees, synchronises or keeps a pointer after
+ *     the call; all work is enqueued on the hipStream_t passed in (void* here so
+ *     the header needs no HIP include);
+ *   - return 0 = OK; < 0 = argument / shape / alignment violation, nothing was
+ *     launched; > 0 = hipError_t from a launch.  moe_last_error() gives the text
+ *     (thread-local);
+ *   - the number of launches per call is fixed; data-dependent sizes (rows kept per
+ *     expert) stay on the device, so every call is graph-capturable.
+ *
+ * "Replaces" citations name the reference call site (files under /root/reference)
+ * and the upstream DeepSpeed function it lands in (deepspeed==0.17.5, not
+ * vendored: environment.yml:74; semantics in SURVEY.md 8a rows a1-a11).
+ */
+#ifndef MOE_GFX950_H
+#define MOE_GFX950_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOE_ABI_VERSION 1
+
+/* activation / expert-MLP form of moe_expert_ffn_fwd */
+#define MOE_ACT_SWIGLU   0 /* h = silu(Wa x) * (Wb x); W1 = [Wa ; Wb] ([2I, M]).  StableLM: Wa=gate_proj, Wb=up_proj
+                              (stablelm/modeling_stablelm_epoch.py:167-168); Qwen: Wa=w2, Wb=w1
+                              (qwen/modeling_qwen.py:601-606)                                                  */
+#define MOE_ACT_GELU_NEW 1 /* h = gelu_new(W1 x + b1), W1 = [I, M] (phi/modeling_phi.py:211-215)               */
+
+/* error codes (negative = nothing launched) */
+#define MOE_OK            0
+#define MOE_ERR_ARG      -1 /* null pointer / bad enum                */
+#define MOE_ERR_SHAPE    -2 /* unsupported shape (see each function)  */
+#define MOE_ERR_ALIGN    -3 /* pointer or stride not 16-byte aligned  */
+#define MOE_ERR_WORKSPACE -4 /* workspace too small                   */
+
+int moe_abi_version(void);
+const char *moe_last_error(void);
+
+/* ---- routing ------------------------------------------------------------------------------
+ * Replaces TopKGate.forward + top2gating, reached from
+ * moellava/model/language_model/llava_stablelm_moe.py:163 via MoE.forward.
+ *
+ * moe_gate_logits_fwd: logits[s,e] = sum_m float(x[s,m]) * float(wg[e,m])  (fp32 accumulate).
+ *   x  [S,M] bf16 row-major (row stride M), M % 8 == 0, E <= 64.
+ *   wg [E,M] fp32 (wg_is_bf16 = 0) or bf16 (1).
+ */
+int moe_gate_logits_fwd(const void *x_bf16, const void *wg, int wg_is_bf16, float *logits,
+                        int S, int M, int E, void *stream);
+
+/* bytes of workspace moe_routing_top2_fwd needs for S tokens and E experts */
+size_t moe_routing_workspace_bytes(int S, int E);
+
+/* moe_routing_top2_fwd: softmax -> top-2 -> capacity positions -> drop -> renormalised weights ->
+ * l_aux / exp_counts -> dispatch index, from fp32 logits.  Index form of SURVEY 8(a').
+ *   logits      [S,E] fp32 (read only)
+ *   noise       [S,E] fp32 or NULL: added to the logits for the SECOND choice only
+ *               (top2_2nd_expert_sampling; NULL = deterministic branch)
+ *   capacity    C, computed on the host exactly as upstream _capacity (ignored when drop_tokens = 0,
+ *               then capacity = max_e exp_counts[e] and nothing is dropped)
+ *   expert_idx  [S,2] int32   chosen experts (first, second)
+ *   slot        [S,2] int32   position in the expert's capacity buffer, -1 = dropped
+ *   weight      [S,2] fp32    normalised combine weights (0 for a dropped choice)
+ *   exp_counts  [E]   int64   tokens routed per expert BEFORE the drop
+ *   kept_counts [E]   int32   rows kept per expert
+ *   expert_offsets [E+1] int32 exclusive prefix of kept_counts
+ *   perm        [min(2S, E*C)] int32  perm[expert_offsets[e] + slot] = token*2 + choice
+ *   l_aux       [1]   fp32
+ * 2 <= E <= 64.  Three launches.
+ */
+int moe_routing_top2_fwd(const float *logits, const float *noise, int S, int E, int capacity,
+                         int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
+                         int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets,
+                         int32_t *perm, float *l_aux, void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- expert FFN ---------------------------------------------------------------------------
+ * Replaces einsum("sec,sm->ecm") dispatch + Experts.forward over the expert MLPs (SURVEY 8a rows
+ * a6, a8-a11): a grouped, variable-length bf16 GEMM pair on MFMA with the activation fused into
+ * the first GEMM's epilogue.  Rows are "compact": group g owns rows [group_offsets[g],
+ * group_offsets[g+1]) and uses expert weights number (g % n_experts_local).
+ *
+ *   act          MOE_ACT_*
+ *   a            source rows, bf16, row stride lda elements
+ *   gather       NULL: compact row p reads a[p];  else compact row p reads a[gather[p] >> gather_shift]
+ *                (gather = perm of moe_routing_top2_fwd, gather_shift = 1)
+ *   w1           [n_experts_local, N1, M] bf16, N1 = 2I (SWIGLU) or I (GELU_NEW)
+ *   b1           [n_experts_local, N1] bf16 or NULL
+ *   w2           [n_experts_local, M, I] bf16
+ *   b2           [n_experts_local, M] bf16 or NULL
+ *   group_offsets [G+1] int32 on the device
+ *   max_rows     host upper bound of group_offsets[G] (sizes the grid and the workspace)
+ *   h_ws         workspace [max_rows, I] bf16
+ *   y            output    [max_rows, M] bf16: y[p] = expert(row p), rounded to bf16 per Linear as the
+ *                reference's nn.Linear modules do
+ * M % 64 == 0, I % 64 == 0, all pointers 16-byte aligned.  Two launches.
+ */
+int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
+                       const void *w1, const void *b1, const void *w2, const void *b2,
+                       const int32_t *group_offsets, int G, int n_experts_local, int max_rows,
+                       int M, int I, void *h_ws, void *y, void *stream);
+
+/* moe_gather_rows_fwd: dst[p] = src[gather[p] >> gather_shift] for p < *n_rows_dev (device int32),
+ * rows of M bf16.  Builds the expert-sorted send buffer of the expert-parallel all-to-all
+ * (replaces the dispatch einsum in front of _AllToAll). */
+int moe_gather_rows_fwd(const void *src, const int32_t *gather, int gather_shift,
+                        const int32_t *n_rows_dev, int max_rows, int M, void *dst, void *stream);
+
+/* moe_combine_fwd: out[s] = bf16( float(bf16(w[s,0])) * y[pos(s,0)] + float(bf16(w[s,1])) * y[pos(s,1)] ),
+ * pos(s,j) = expert_offsets[expert_idx[s,j]] + slot[s,j]; a dropped choice contributes 0.
+ * Replaces einsum("sec,ecm->sm", combine_weights.type_as(x), expert_output).
+ * out [S,M] bf16 is fully overwritten.  M % 8 == 0.  top_k = 1 or 2 (columns of the [S,top_k] arrays). */
+int moe_combine_fwd(const void *y, const int32_t *expert_idx, const int32_t *slot, const float *weight,
+                    const int32_t *expert_offsets, int S, int M, int top_k, void *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOE_GFX950_H */

@@ -1,0 +1,48 @@
+"""Build libmoe_gfx950.so in-tree with plain hipcc (no torch extension, no pybind): the C ABI of
+``include/moe_gfx950.h`` is the whole interface.  ``python -m moe_llava_amd.build`` or
+``__graft_entry__.build()``."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libmoe_gfx950.so")
+SOURCES = ["moe_routing.hip", "moe_gemm.hip"]
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(os.path.dirname(PKG_DIR), "include", "moe_gfx950.h"))
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", *extra_flags,
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
+    if verbose:
+        print("[moe_llava_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv,
+                  extra_flags=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
+    print(LIB_PATH)

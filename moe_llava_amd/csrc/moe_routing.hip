@@ -1,0 +1,474 @@
+// Routing kernels for the sparse-MoE FFN block on gfx950:
+//   gate GEMV (fp32 logits) -> softmax -> top-2 -> per-expert prefix-scan positions -> capacity drop
+//   -> renormalised weights, l_aux, exp_counts, dispatch index (perm + expert_offsets).
+// They replace TopKGate.forward / top2gating of deepspeed.moe.sharded_moe (SURVEY.md 8a rows a3-a5,
+// index form 8a'), i.e. the dense [S,E,C] one-hot / cumsum / einsum mask pipeline.
+//
+// All kernels are HBM- or latency-bound integer/fp32 work: wave64 ballots give the in-wave ranks,
+// LDS holds the per-wave histograms, one small single-block kernel scans the per-block histograms.
+#include "moe_common.h"
+
+namespace moe {
+
+static thread_local char g_err[512];
+char *err_buf() { return g_err; }
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+constexpr int RB = 256;  // tokens (= threads) per routing block
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gate GEMV: one wave computes R rows x E experts; lanes split M in 16-byte pieces of x.
+// Algorithmic bytes: S*M*2 (x) + E*M*4 (wg, L2-resident) + S*E*4 (logits).
+// ------------------------------------------------------------------------------------------------
+template <int EMAX, int R, bool WG_BF16>
+__global__ __launch_bounds__(256) void gate_logits_kernel(const bf16_t *__restrict__ x, const void *__restrict__ wg,
+                                                          float *__restrict__ logits, int S, int M, int E) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + wave) * R;
+    if (row0 >= S) return;
+    float acc[R][EMAX];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) acc[r][e] = 0.f;
+
+    for (int m0 = lane * 8; m0 < M; m0 += 64 * 8) {
+        float xf[R][8];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int row = row0 + r;
+            if (row > S - 1) row = S - 1;
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + (size_t)row * M + m0);
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xf[r][2 * j] = __builtin_bit_cast(float, u[j] << 16);
+                xf[r][2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            if (e < E) {
+                float w[8];
+                if (WG_BF16) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(wg) + (size_t)e * M + m0);
+                    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        w[2 * j] = __builtin_bit_cast(float, u[j] << 16);
+                        w[2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xffff0000u);
+                    }
+                } else {
+                    const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(wg) + (size_t)e * M + m0);
+                    const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(wg) + (size_t)e * M + m0 + 4);
+                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+                    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[r][e] = fmaf(xf[r][j], w[j], acc[r][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            if (e < E) {
+                const float v = wave_sum(acc[r][e]);
+                if (lane == 0 && row0 + r < S) logits[(size_t)(row0 + r) * E + e] = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// routing pass 1: per token softmax + top-2; per block (256 tokens) ranks, histograms, gate sums.
+// Temporaries are parked in the output arrays: slot <- rank inside the block, weight <- raw gates.
+// ------------------------------------------------------------------------------------------------
+template <int EMAX>
+__global__ __launch_bounds__(RB) void route_local_kernel(const float *__restrict__ logits, const float *__restrict__ noise,
+                                                         int S, int E, int nb, int *__restrict__ expert_idx,
+                                                         int *__restrict__ slot, float *__restrict__ weight,
+                                                         int *__restrict__ hist, float *__restrict__ gsum) {
+    __shared__ int wcnt[2][RB / 64][EMAX];
+    __shared__ float wsum[RB / 64][EMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x * RB + tid;
+    const bool valid = s < S;
+
+    float l[EMAX], g[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) l[e] = (valid && e < E) ? logits[(size_t)s * E + e] : -INFINITY;
+    float mx = l[0];
+#pragma unroll
+    for (int e = 1; e < EMAX; ++e) mx = fmaxf(mx, l[e]);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        g[e] = (e < E) ? expf(l[e] - mx) : 0.f;
+        sum += g[e];  // index order
+    }
+    int i1 = 0;
+    float g1 = -1.f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        g[e] = g[e] / sum;  // IEEE division (hipcc default: correctly rounded)
+        if (e < E && g[e] > g1) { g1 = g[e]; i1 = e; }  // strict > : lowest index wins ties
+    }
+    int i2 = 0;
+    float best = -INFINITY, g2 = 0.f;
+    bool have2 = false;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        if (e < E && e != i1) {
+            float v = l[e];
+            if (noise != nullptr && valid) v += noise[(size_t)s * E + e];
+            // the first candidate is always taken; after that strict > keeps the lowest index on ties
+            if (!have2 || v > best) { best = v; i2 = e; g2 = g[e]; have2 = true; }
+        }
+    }
+    if (!valid) { i1 = -1; i2 = -1; }
+
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int r1 = 0, r2 = 0;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        if (e < E) {
+            const unsigned long long b1 = __ballot(i1 == e);
+            const unsigned long long b2 = __ballot(i2 == e);
+            if (i1 == e) r1 = __popcll(b1 & lt);
+            if (i2 == e) r2 = __popcll(b2 & lt);
+            const float gs = wave_sum(valid ? g[e] : 0.f);
+            if (lane == 0) {
+                wcnt[0][wave][e] = __popcll(b1);
+                wcnt[1][wave][e] = __popcll(b2);
+                wsum[wave][e] = gs;
+            }
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        for (int w = 0; w < wave; ++w) {
+            r1 += wcnt[0][w][i1];
+            r2 += wcnt[1][w][i2];
+        }
+        reinterpret_cast<int2 *>(expert_idx)[s] = make_int2(i1, i2);
+        reinterpret_cast<int2 *>(slot)[s] = make_int2(r1, r2);
+        reinterpret_cast<float2 *>(weight)[s] = make_float2(g1, g2);
+    }
+    if (tid < E) {
+        int c1 = 0, c2 = 0;
+        float gs = 0.f;
+#pragma unroll
+        for (int w = 0; w < RB / 64; ++w) {
+            c1 += wcnt[0][w][tid];
+            c2 += wcnt[1][w][tid];
+            gs += wsum[w][tid];
+        }
+        hist[(size_t)tid * nb + blockIdx.x] = c1;
+        hist[(size_t)(E + tid) * nb + blockIdx.x] = c2;
+        gsum[(size_t)tid * nb + blockIdx.x] = gs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// routing pass 2 (one block): exclusive scan of the per-block histograms (in place), totals,
+// exp_counts, kept_counts, expert_offsets, l_aux.  meta = {capacity_eff, n1[E]}.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void route_scan_kernel(int *__restrict__ hist, const float *__restrict__ gsum, int S, int E,
+                                                          int nb, int capacity, int drop_tokens,
+                                                          long long *__restrict__ exp_counts, int *__restrict__ kept_counts,
+                                                          int *__restrict__ expert_offsets, float *__restrict__ l_aux,
+                                                          int *__restrict__ meta) {
+    __shared__ int tot[128];
+    __shared__ float gtot[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int q = wave; q < 2 * E; q += nw) {
+        int carry = 0;
+        int *h = hist + (size_t)q * nb;
+        for (int c0 = 0; c0 < nb; c0 += 64) {
+            const int i = c0 + lane;
+            const int v = (i < nb) ? h[i] : 0;
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
+            }
+            if (i < nb) h[i] = carry + inc - v;
+            carry += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) tot[q] = carry;
+    }
+    for (int e = wave; e < E; e += nw) {
+        double acc = 0.0;
+        const float *gp = gsum + (size_t)e * nb;
+        for (int c0 = 0; c0 < nb; c0 += 64) {
+            const int i = c0 + lane;
+            acc += wave_sum_d((i < nb) ? (double)gp[i] : 0.0);
+        }
+        if (lane == 0) gtot[e] = (float)acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int cap = capacity;
+        if (!drop_tokens) {
+            cap = 0;
+            for (int e = 0; e < E; ++e) cap = max(cap, tot[e] + tot[E + e]);
+        }
+        meta[0] = cap;
+        int off = 0;
+        float lsum = 0.f;
+        const float fS = (float)S;
+        for (int e = 0; e < E; ++e) {
+            const int n1 = tot[e], n2 = tot[E + e];
+            exp_counts[e] = (long long)n1 + (long long)n2;
+            const int k1 = min(n1, cap);
+            const int k2 = max(0, min(n2, cap - n1));
+            kept_counts[e] = k1 + k2;
+            expert_offsets[e] = off;
+            off += k1 + k2;
+            meta[1 + e] = n1;
+            const float me = gtot[e] / fS;
+            const float ce = (float)n1 / fS;
+            lsum += me * ce;
+        }
+        expert_offsets[E] = off;
+        const float fE = (float)E;
+        l_aux[0] = ((lsum / fE) * fE) * fE;  // mean(me*ce) * E * E, op order as upstream
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// routing pass 3: global positions, capacity drop, renormalised weights, dispatch index.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void route_finalize_kernel(int S, int E, int nb, const int *__restrict__ hist,
+                                                            const int *__restrict__ meta,
+                                                            const int *__restrict__ expert_offsets,
+                                                            const int *__restrict__ expert_idx, int *__restrict__ slot,
+                                                            float *__restrict__ weight, int *__restrict__ perm) {
+    const int s = blockIdx.x * RB + threadIdx.x;
+    if (s >= S) return;
+    const int cap = meta[0];
+    const int2 ix = reinterpret_cast<const int2 *>(expert_idx)[s];
+    const int2 rk = reinterpret_cast<const int2 *>(slot)[s];
+    const float2 gg = reinterpret_cast<const float2 *>(weight)[s];
+    const int p1 = hist[(size_t)ix.x * nb + blockIdx.x] + rk.x;
+    const int p2 = meta[1 + ix.y] + hist[(size_t)(E + ix.y) * nb + blockIdx.x] + rk.y;
+    const bool k1 = p1 < cap, k2 = p2 < cap;
+    const float g1 = k1 ? gg.x : 0.f, g2 = k2 ? gg.y : 0.f;
+    const float den = fmaxf(g1 + g2, 1.1920928955078125e-07f);  // clamp(min = finfo(fp32).eps)
+    reinterpret_cast<float2 *>(weight)[s] = make_float2(g1 / den, g2 / den);
+    reinterpret_cast<int2 *>(slot)[s] = make_int2(k1 ? p1 : -1, k2 ? p2 : -1);
+    if (k1) perm[expert_offsets[ix.x] + p1] = 2 * s;
+    if (k2) perm[expert_offsets[ix.y] + p2] = 2 * s + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row gather (expert-parallel send buffer) and weighted combine.  Both stream whole rows, 16 B per lane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t *__restrict__ src, const int *__restrict__ gather,
+                                                          int gather_shift, const int *__restrict__ n_rows_dev,
+                                                          int max_rows, int M, bf16_t *__restrict__ dst) {
+    int n = *n_rows_dev;
+    if (n > max_rows) n = max_rows;
+    const int chunks = M >> 3;
+    for (int p = blockIdx.x; p < n; p += gridDim.x) {
+        const size_t srow = (size_t)(gather[p] >> gather_shift);
+        const uint4 *sp = reinterpret_cast<const uint4 *>(src + srow * M);
+        uint4 *dp = reinterpret_cast<uint4 *>(dst + (size_t)p * M);
+        for (int c = threadIdx.x; c < chunks; c += blockDim.x) dp[c] = sp[c];
+    }
+}
+
+template <int TOPK>
+__global__ __launch_bounds__(256) void combine_kernel(const bf16_t *__restrict__ y, const int *__restrict__ expert_idx,
+                                                      const int *__restrict__ slot, const float *__restrict__ weight,
+                                                      const int *__restrict__ expert_offsets, int S, int M,
+                                                      bf16_t *__restrict__ out) {
+    const int chunks = M >> 3;
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        const uint4 *src[TOPK];
+        float w[TOPK];
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) {
+            const int sl = slot[s * TOPK + j];
+            const float wq = rbf(weight[s * TOPK + j]);  // combine_weights.type_as(x)
+            const bool on = sl >= 0 && wq != 0.f;
+            w[j] = on ? wq : 0.f;
+            const size_t pos = on ? (size_t)(expert_offsets[expert_idx[s * TOPK + j]] + sl) : 0;
+            src[j] = on ? reinterpret_cast<const uint4 *>(y + pos * M) : nullptr;
+        }
+        uint4 *dp = reinterpret_cast<uint4 *>(out + (size_t)s * M);
+        for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j) {
+                if (src[j] != nullptr) {
+                    const uint4 v = src[j][c];
+                    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // bf16*bf16 products are exact in fp32, so the two-term sum rounds once
+                        acc[2 * i] += w[j] * __builtin_bit_cast(float, u[i] << 16);
+                        acc[2 * i + 1] += w[j] * __builtin_bit_cast(float, u[i] & 0xffff0000u);
+                    }
+                }
+            }
+            uint4 o;
+            o.x = (unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16);
+            o.y = (unsigned)f2bf(acc[2]) | ((unsigned)f2bf(acc[3]) << 16);
+            o.z = (unsigned)f2bf(acc[4]) | ((unsigned)f2bf(acc[5]) << 16);
+            o.w = (unsigned)f2bf(acc[6]) | ((unsigned)f2bf(acc[7]) << 16);
+            dp[c] = o;
+        }
+    }
+}
+
+static inline size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
+
+struct RoutingWs {
+    int *hist;
+    float *gsum;
+    int *meta;
+    size_t total;
+};
+static RoutingWs carve(void *ws, int S, int E) {
+    const size_t nb = (size_t)(S + RB - 1) / RB;
+    RoutingWs r;
+    size_t off = 0;
+    r.hist = reinterpret_cast<int *>((char *)ws + off);
+    off += pad16(sizeof(int) * 2 * E * nb);
+    r.gsum = reinterpret_cast<float *>((char *)ws + off);
+    off += pad16(sizeof(float) * E * nb);
+    r.meta = reinterpret_cast<int *>((char *)ws + off);
+    off += pad16(sizeof(int) * (1 + E));
+    r.total = off;
+    return r;
+}
+
+}  // namespace moe
+
+using namespace moe;
+
+extern "C" int moe_abi_version(void) { return MOE_ABI_VERSION; }
+extern "C" const char *moe_last_error(void) { return err_buf(); }
+
+extern "C" int moe_gate_logits_fwd(const void *x, const void *wg, int wg_is_bf16, float *logits, int S, int M, int E,
+                                   void *stream) {
+    if (!x || !wg || !logits) return fail(MOE_ERR_ARG, "moe_gate_logits_fwd: null pointer");
+    if (S < 0 || M <= 0 || (M & 7) || E < 1 || E > 64)
+        return fail(MOE_ERR_SHAPE, "moe_gate_logits_fwd: need S>=0, M%%8==0, 1<=E<=64 (S=%d M=%d E=%d)", S, M, E);
+    if (!aligned16(x) || !aligned16(wg)) return fail(MOE_ERR_ALIGN, "moe_gate_logits_fwd: x / wg not 16-byte aligned");
+    if (S == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t *xp = (const bf16_t *)x;
+#define LAUNCH_GATE(EM, RR)                                                                                      \
+    do {                                                                                                         \
+        const int rows_per_block = 4 * RR;                                                                       \
+        dim3 grid((S + rows_per_block - 1) / rows_per_block);                                                    \
+        if (wg_is_bf16)                                                                                          \
+            hipLaunchKernelGGL((gate_logits_kernel<EM, RR, true>), grid, dim3(256), 0, st, xp, wg, logits, S, M, E); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((gate_logits_kernel<EM, RR, false>), grid, dim3(256), 0, st, xp, wg, logits, S, M, E); \
+    } while (0)
+    if (E <= 4) LAUNCH_GATE(4, 4);
+    else if (E <= 8) LAUNCH_GATE(8, 4);
+    else if (E <= 16) LAUNCH_GATE(16, 2);
+    else LAUNCH_GATE(64, 1);
+#undef LAUNCH_GATE
+    return check_launch("gate_logits_kernel");
+}
+
+extern "C" size_t moe_routing_workspace_bytes(int S, int E) {
+    if (S < 0 || E < 1) return 0;
+    return carve(nullptr, S, E).total;
+}
+
+extern "C" int moe_routing_top2_fwd(const float *logits, const float *noise, int S, int E, int capacity, int drop_tokens,
+                                    int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
+                                    int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
+                                    void *workspace, size_t ws_bytes, void *stream) {
+    if (!logits || !expert_idx || !slot || !weight || !exp_counts || !kept_counts || !expert_offsets || !perm || !l_aux ||
+        !workspace)
+        return fail(MOE_ERR_ARG, "moe_routing_top2_fwd: null pointer");
+    if (S < 1 || E < 2 || E > 64)
+        return fail(MOE_ERR_SHAPE, "moe_routing_top2_fwd: need S>=1 and 2<=E<=64 (S=%d E=%d)", S, E);
+    if (drop_tokens && capacity < 0) return fail(MOE_ERR_SHAPE, "moe_routing_top2_fwd: negative capacity");
+    if (!aligned16(workspace) || ((uintptr_t)expert_idx & 7) || ((uintptr_t)slot & 7) || ((uintptr_t)weight & 7))
+        return fail(MOE_ERR_ALIGN, "moe_routing_top2_fwd: workspace needs 16-byte, [S,2] arrays 8-byte alignment");
+    RoutingWs ws = carve(workspace, S, E);
+    if (ws_bytes < ws.total)
+        return fail(MOE_ERR_WORKSPACE, "moe_routing_top2_fwd: workspace %zu < %zu bytes", ws_bytes, ws.total);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (S + RB - 1) / RB;
+#define LAUNCH_LOCAL(EM)                                                                                              \
+    hipLaunchKernelGGL((route_local_kernel<EM>), dim3(nb), dim3(RB), 0, st, logits, noise, S, E, nb, expert_idx, slot, \
+                       weight, ws.hist, ws.gsum)
+    if (E <= 4) LAUNCH_LOCAL(4);
+    else if (E <= 8) LAUNCH_LOCAL(8);
+    else if (E <= 16) LAUNCH_LOCAL(16);
+    else LAUNCH_LOCAL(64);
+#undef LAUNCH_LOCAL
+    int rc = check_launch("route_local_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, st, ws.hist, ws.gsum, S, E, nb, capacity, drop_tokens,
+                       (long long *)exp_counts, kept_counts, expert_offsets, l_aux, ws.meta);
+    rc = check_launch("route_scan_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(route_finalize_kernel, dim3(nb), dim3(RB), 0, st, S, E, nb, ws.hist, ws.meta, expert_offsets,
+                       expert_idx, slot, weight, perm);
+    return check_launch("route_finalize_kernel");
+}
+
+extern "C" int moe_gather_rows_fwd(const void *src, const int32_t *gather, int gather_shift, const int32_t *n_rows_dev,
+                                   int max_rows, int M, void *dst, void *stream) {
+    if (!src || !gather || !n_rows_dev || !dst) return fail(MOE_ERR_ARG, "moe_gather_rows_fwd: null pointer");
+    if (max_rows < 0 || M <= 0 || (M & 7) || gather_shift < 0 || gather_shift > 1)
+        return fail(MOE_ERR_SHAPE, "moe_gather_rows_fwd: need M%%8==0, gather_shift in {0,1}");
+    if (!aligned16(src) || !aligned16(dst)) return fail(MOE_ERR_ALIGN, "moe_gather_rows_fwd: src / dst not 16-byte aligned");
+    if (max_rows == 0) return 0;
+    const int grid = max_rows < 8192 ? max_rows : 8192;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)src, gather,
+                       gather_shift, n_rows_dev, max_rows, M, (bf16_t *)dst);
+    return check_launch("gather_rows_kernel");
+}
+
+extern "C" int moe_combine_fwd(const void *y, const int32_t *expert_idx, const int32_t *slot, const float *weight,
+                               const int32_t *expert_offsets, int S, int M, int top_k, void *out, void *stream) {
+    if (!y || !expert_idx || !slot || !weight || !expert_offsets || !out)
+        return fail(MOE_ERR_ARG, "moe_combine_fwd: null pointer");
+    if (S < 0 || M <= 0 || (M & 7) || (top_k != 1 && top_k != 2))
+        return fail(MOE_ERR_SHAPE, "moe_combine_fwd: need M%%8==0 and top_k in {1,2}");
+    if (!aligned16(y) || !aligned16(out)) return fail(MOE_ERR_ALIGN, "moe_combine_fwd: y / out not 16-byte aligned");
+    if (S == 0) return 0;
+    const int grid = S < 16384 ? S : 16384;
+    hipStream_t st = (hipStream_t)stream;
+    if (top_k == 2)
+        hipLaunchKernelGGL((combine_kernel<2>), dim3(grid), dim3(256), 0, st, (const bf16_t *)y, expert_idx, slot, weight,
+                           expert_offsets, S, M, (bf16_t *)out);
+    else
+        hipLaunchKernelGGL((combine_kernel<1>), dim3(grid), dim3(256), 0, st, (const bf16_t *)y, expert_idx, slot, weight,
+                           expert_offsets, S, M, (bf16_t *)out);
+    return check_launch("combine_kernel");
+}

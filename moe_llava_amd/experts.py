@@ -1,0 +1,175 @@
+"""``Experts``: drop-in for ``deepspeed.moe.experts.Experts``.
+
+Keeps the reference-visible structure -- ``deepspeed_experts`` is an ``nn.ModuleList`` of deep copies of
+the expert passed in, every parameter tagged ``allreduce=False`` / ``group_name`` (read by
+``moellava/train/llava_trainer.py:822-824`` and ``llava_stablelm_moe.py:693-699``) -- while the grouped
+GEMM wants one contiguous ``[E_local, N, K]`` buffer per projection.  Both hold: the packed buffers are
+allocated once and every expert ``nn.Linear`` parameter is re-pointed to a *view* into them, so
+``state_dict()`` / ``load_state_dict()`` / in-place optimizer updates hit the packed memory directly.
+A cheap ``data_ptr`` check per forward re-packs after ``.to()`` / ``.cuda()`` replaced the storage.
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+
+
+@dataclass
+class ExpertSpec:
+    """How one expert module maps onto the kernel's two GEMMs."""
+    act: int                      # ops.ACT_*
+    fc1: List[nn.Linear]          # SWIGLU: [a (silu'd), b]; GELU_NEW: [fc1]
+    fc2: nn.Linear
+
+
+_ADAPTERS: List[Callable[[nn.Module], Optional[ExpertSpec]]] = []
+
+
+def register_expert_adapter(fn: Callable[[nn.Module], Optional[ExpertSpec]]) -> None:
+    """Register a function mapping an expert module to an ``ExpertSpec`` (or None if it does not apply)."""
+    _ADAPTERS.insert(0, fn)
+
+
+def _is_linear(m) -> bool:
+    return isinstance(m, nn.Linear)
+
+
+def _act_name(m) -> str:
+    return type(m).__name__.lower() if m is not None else ""
+
+
+def _adapt_builtin(e: nn.Module) -> Optional[ExpertSpec]:
+    # StableLM / LLaMA / Mistral / MiniCPM form: down_proj(act_fn(gate_proj(x)) * up_proj(x))
+    # (stablelm/modeling_stablelm_epoch.py:156-168)
+    if all(_is_linear(getattr(e, n, None)) for n in ("gate_proj", "up_proj", "down_proj")):
+        act = getattr(e, "act_fn", None)
+        if act is not None and "silu" not in _act_name(act) and "swish" not in _act_name(act):
+            raise NotImplementedError(f"gated expert with activation {type(act).__name__}: only SiLU is implemented")
+        return ExpertSpec(ops.ACT_SWIGLU, [e.gate_proj, e.up_proj], e.down_proj)
+    # Qwen form: c_proj(w1(x) * silu(w2(x)))  (qwen/modeling_qwen.py:589-606): the silu'd projection is w2
+    if all(_is_linear(getattr(e, n, None)) for n in ("w1", "w2", "c_proj")):
+        return ExpertSpec(ops.ACT_SWIGLU, [e.w2, e.w1], e.c_proj)
+    # Phi form: fc2(gelu_new(fc1(x)))  (phi/modeling_phi.py:203-215)
+    if all(_is_linear(getattr(e, n, None)) for n in ("fc1", "fc2")):
+        act = getattr(e, "activation_fn", None)
+        name = _act_name(act)
+        if "newgelu" not in name and "gelunew" not in name and "gelu_new" not in name:
+            raise NotImplementedError(
+                f"fc1/fc2 expert with activation {type(act).__name__}: only gelu_new (tanh form) is implemented")
+        return ExpertSpec(ops.ACT_GELU_NEW, [e.fc1], e.fc2)
+    return None
+
+
+def describe_expert(e: nn.Module) -> ExpertSpec:
+    for fn in _ADAPTERS + [_adapt_builtin]:
+        spec = fn(e)
+        if spec is not None:
+            return spec
+    raise NotImplementedError(
+        f"moe_llava_amd has no kernel mapping for expert module {type(e).__name__}; "
+        "register one with moe_llava_amd.experts.register_expert_adapter (there is no eager fallback)")
+
+
+class Experts(nn.Module):
+    def __init__(self, expert: nn.Module, num_local_experts: int = 1, expert_group_name: Optional[str] = None):
+        super().__init__()
+        self.deepspeed_experts = nn.ModuleList([copy.deepcopy(expert) for _ in range(num_local_experts)])
+        self.num_local_experts = num_local_experts
+        self.expert_group_name = expert_group_name
+        for e in self.deepspeed_experts:
+            for p in e.parameters():
+                p.allreduce = False
+                p.group_name = expert_group_name
+        self._packed: Optional[Dict[str, Optional[Tensor]]] = None
+        self._ptrs: Optional[List[int]] = None
+
+    # ---- packed weights ----------------------------------------------------------------------
+    def _specs(self) -> List[ExpertSpec]:
+        specs = [describe_expert(e) for e in self.deepspeed_experts]
+        a0, n0 = specs[0].act, len(specs[0].fc1)
+        for s in specs:
+            if s.act != a0 or len(s.fc1) != n0:
+                raise ValueError("all local experts must share one MLP form")
+        return specs
+
+    def _params(self, specs) -> List[nn.Parameter]:
+        ps = []
+        for s in specs:
+            for lin in s.fc1 + [s.fc2]:
+                ps.append(lin.weight)
+                if lin.bias is not None:
+                    ps.append(lin.bias)
+        return ps
+
+    def packed(self, device: torch.device):
+        """Return (act, w1 [E,N1,M], b1|None, w2 [E,M,I], b2|None), (re)packing when a parameter's storage moved."""
+        specs = self._specs()
+        params = self._params(specs)
+        ptrs = [p.data_ptr() for p in params]
+        if self._packed is not None and ptrs == self._ptrs and self._packed["w1"].device == device:
+            pk = self._packed
+            return specs[0].act, pk["w1"], pk["b1"], pk["w2"], pk["b2"]
+        for p in params:
+            if p.dtype != torch.bfloat16:
+                raise TypeError(f"expert parameters must be bf16 (got {p.dtype}); cast the model with .to(torch.bfloat16)")
+            if p.device != device:
+                raise ValueError(f"expert parameter on {p.device}, activations on {device}")
+        E = len(specs)
+        I, M = specs[0].fc1[0].weight.shape
+        nproj = len(specs[0].fc1)
+        for s in specs:
+            for lin in s.fc1:
+                if tuple(lin.weight.shape) != (I, M):
+                    raise ValueError("fc1 projections of all local experts must have equal shapes")
+            if tuple(s.fc2.weight.shape) != (M, I):
+                raise ValueError(f"fc2 weight {tuple(s.fc2.weight.shape)} does not match {(M, I)}")
+        if M % 64 or I % 64:
+            raise ValueError(f"kernel needs hidden size and expert width to be multiples of 64 (M={M}, I={I})")
+        has_b1 = specs[0].fc1[0].bias is not None
+        has_b2 = specs[0].fc2.bias is not None
+        kw = dict(dtype=torch.bfloat16, device=device)
+        w1 = torch.empty((E, nproj * I, M), **kw)
+        w2 = torch.empty((E, M, I), **kw)
+        b1 = torch.empty((E, nproj * I), **kw) if has_b1 else None
+        b2 = torch.empty((E, M), **kw) if has_b2 else None
+        with torch.no_grad():
+            for i, s in enumerate(specs):
+                for j, lin in enumerate(s.fc1):
+                    if (lin.bias is not None) != has_b1:
+                        raise ValueError("bias must be present on all fc1 projections or none")
+                    v = w1[i, j * I:(j + 1) * I]
+                    v.copy_(lin.weight.data)
+                    lin.weight.data = v
+                    if has_b1:
+                        bv = b1[i, j * I:(j + 1) * I]
+                        bv.copy_(lin.bias.data)
+                        lin.bias.data = bv
+                if (s.fc2.bias is not None) != has_b2:
+                    raise ValueError("bias must be present on all fc2 projections or none")
+                w2[i].copy_(s.fc2.weight.data)
+                s.fc2.weight.data = w2[i]
+                if has_b2:
+                    b2[i].copy_(s.fc2.bias.data)
+                    s.fc2.bias.data = b2[i]
+        self._packed = {"w1": w1, "b1": b1, "w2": w2, "b2": b2}
+        self._ptrs = [p.data_ptr() for p in self._params(specs)]
+        return specs[0].act, w1, b1, w2, b2
+
+    # ---- reference-shaped forward -------------------------------------------------------------
+    def forward(self, inputs: Tensor) -> Tensor:
+        """``inputs`` [ep, E_local, C, M] (upstream layout): expert ``le`` processes ``inputs[:, le]``.
+        Runs the grouped HIP FFN over the ep*E_local equal groups of C rows."""
+        if inputs.dim() != 4 or inputs.shape[1] != self.num_local_experts:
+            raise ValueError(f"Experts.forward expects [ep, {self.num_local_experts}, C, M], got {tuple(inputs.shape)}")
+        ep, el, C, M = inputs.shape
+        flat = inputs.contiguous().reshape(ep * el * C, M)
+        act, w1, b1, w2, b2 = self.packed(flat.device)
+        offs = torch.arange(0, (ep * el + 1) * C, C, dtype=torch.int32, device=flat.device)
+        y = ops.expert_ffn(act, flat, None, 0, w1, b1, w2, b2, offs, ep * el * C)
+        return y[: ep * el * C].reshape(ep, el, C, M)

@@ -1,0 +1,183 @@
+"""Host-side wrappers of the C ABI: shape / dtype / device validation, buffer allocation through the
+torch caching allocator (so every buffer is stream-ordered on the current stream), and the launch.
+
+Nothing here computes on the CPU or in eager torch; a missing library raises (``_lib.load``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+ACT_SWIGLU = 0
+ACT_GELU_NEW = 1
+
+
+def _stream_ptr(t: Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need(t: Tensor, name: str, dtype, ndim: Optional[int] = None) -> None:
+    if not isinstance(t, Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise _lib.MoEKernelError(f"{name}: must live on the GPU (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+
+
+@dataclass
+class Routing:
+    """Index-form routing result (SURVEY 8a').  All tensors live on the device."""
+    expert_idx: Tensor      # [S,2] int32
+    slot: Tensor            # [S,2] int32, -1 = dropped
+    weight: Tensor          # [S,2] fp32
+    exp_counts: Tensor      # [E] int64 (pre-drop)
+    kept_counts: Tensor     # [E] int32
+    expert_offsets: Tensor  # [E+1] int32
+    perm: Tensor            # [max_rows] int32, token*2+choice
+    l_aux: Tensor           # 0-dim fp32
+    max_rows: int           # host bound on expert_offsets[E]
+    capacity: int
+
+
+def gate_logits(x: Tensor, wg_weight: Tensor) -> Tensor:
+    """logits = x.float() @ wg.float().T  ([S,E] fp32) -- TopKGate.forward's F.linear."""
+    _need(x, "x", torch.bfloat16, 2)
+    if wg_weight.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"wg.weight: expected fp32 or bf16, got {wg_weight.dtype}")
+    _need(wg_weight, "wg.weight", wg_weight.dtype, 2)
+    S, M = x.shape
+    E = wg_weight.shape[0]
+    if wg_weight.shape[1] != M or wg_weight.device != x.device:
+        raise ValueError(f"wg.weight {tuple(wg_weight.shape)} on {wg_weight.device} does not match x {tuple(x.shape)} on {x.device}")
+    logits = torch.empty((S, E), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        rc = lib.moe_gate_logits_fwd(x.data_ptr(), wg_weight.data_ptr(), int(wg_weight.dtype == torch.bfloat16),
+                                     logits.data_ptr(), S, M, E, _stream_ptr(x))
+    _lib.check(rc, "moe_gate_logits_fwd")
+    return logits
+
+
+def routing_top2(logits: Tensor, capacity: int, noise: Optional[Tensor] = None,
+                 drop_tokens: bool = True) -> Routing:
+    """top2gating in index form from fp32 logits (SURVEY 8a row a5 / 8a')."""
+    _need(logits, "logits", torch.float32, 2)
+    S, E = logits.shape
+    if S < 1:
+        raise ValueError("routing needs at least one token")
+    if noise is not None:
+        _need(noise, "noise", torch.float32, 2)
+        if noise.shape != logits.shape or noise.device != logits.device:
+            raise ValueError("noise must match logits in shape and device")
+    dev = logits.device
+    max_rows = min(2 * S, E * int(capacity)) if drop_tokens else 2 * S
+    i32 = dict(dtype=torch.int32, device=dev)
+    expert_idx = torch.empty((S, 2), **i32)
+    slot = torch.empty((S, 2), **i32)
+    weight = torch.empty((S, 2), dtype=torch.float32, device=dev)
+    exp_counts = torch.empty((E,), dtype=torch.int64, device=dev)
+    kept = torch.empty((E,), **i32)
+    offs = torch.empty((E + 1,), **i32)
+    perm = torch.empty((max(max_rows, 1),), **i32)
+    l_aux = torch.empty((), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    ws_bytes = lib.moe_routing_workspace_bytes(S, E)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.moe_routing_top2_fwd(logits.data_ptr(), noise.data_ptr() if noise is not None else None,
+                                      S, E, int(capacity), int(bool(drop_tokens)),
+                                      expert_idx.data_ptr(), slot.data_ptr(), weight.data_ptr(),
+                                      exp_counts.data_ptr(), kept.data_ptr(), offs.data_ptr(), perm.data_ptr(),
+                                      l_aux.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(logits))
+    _lib.check(rc, "moe_routing_top2_fwd")
+    return Routing(expert_idx, slot, weight, exp_counts, kept, offs, perm, l_aux, max_rows, int(capacity))
+
+
+def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
+               w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
+               group_offsets: Tensor, max_rows: int) -> Tensor:
+    """Grouped expert MLP over compact rows; returns y [max_rows, M] bf16 (rows past the device-side
+    group_offsets[G] are left unwritten)."""
+    _need(a, "a", torch.bfloat16, 2)
+    _need(w1, "w1", torch.bfloat16, 3)
+    _need(w2, "w2", torch.bfloat16, 3)
+    _need(group_offsets, "group_offsets", torch.int32, 1)
+    M = a.shape[1]
+    n_local, M2, I = w2.shape
+    n1 = 2 * I if act == ACT_SWIGLU else I
+    if M2 != M or tuple(w1.shape) != (n_local, n1, M):
+        raise ValueError(f"weight shapes w1 {tuple(w1.shape)} / w2 {tuple(w2.shape)} do not match M={M}, act={act}")
+    for b, name, n in ((b1, "b1", n1), (b2, "b2", M)):
+        if b is not None:
+            _need(b, name, torch.bfloat16, 2)
+            if tuple(b.shape) != (n_local, n):
+                raise ValueError(f"{name}: expected {(n_local, n)}, got {tuple(b.shape)}")
+    G = group_offsets.numel() - 1
+    if G < 1:
+        raise ValueError("group_offsets needs at least 2 entries")
+    if gather is not None:
+        _need(gather, "gather", torch.int32, 1)
+        if gather.numel() < max_rows:
+            raise ValueError("gather shorter than max_rows")
+    elif a.shape[0] < max_rows:
+        raise ValueError("a has fewer rows than max_rows")
+    for t in (w1, w2, group_offsets, gather, b1, b2):
+        if t is not None and t.device != a.device:
+            raise ValueError("all operands must be on the same device")
+    dev = a.device
+    y = torch.empty((max(max_rows, 1), M), dtype=torch.bfloat16, device=dev)
+    if max_rows == 0:
+        return y
+    h = torch.empty((max_rows, I), dtype=torch.bfloat16, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.moe_expert_ffn_fwd(act, a.data_ptr(), a.stride(0), gather.data_ptr() if gather is not None else None,
+                                    gather_shift, w1.data_ptr(), b1.data_ptr() if b1 is not None else None,
+                                    w2.data_ptr(), b2.data_ptr() if b2 is not None else None,
+                                    group_offsets.data_ptr(), G, n_local, max_rows, M, I,
+                                    h.data_ptr(), y.data_ptr(), _stream_ptr(a))
+    _lib.check(rc, "moe_expert_ffn_fwd")
+    return y
+
+
+def gather_rows(src: Tensor, gather: Tensor, gather_shift: int, n_rows_dev: Tensor, max_rows: int) -> Tensor:
+    """dst[p] = src[gather[p] >> shift] for p < n_rows_dev[0] (expert-sorted send buffer of the EP all-to-all)."""
+    _need(src, "src", torch.bfloat16, 2)
+    _need(gather, "gather", torch.int32, 1)
+    _need(n_rows_dev, "n_rows_dev", torch.int32)
+    if gather.numel() < max_rows:
+        raise ValueError("gather shorter than max_rows")
+    dst = torch.empty((max(max_rows, 1), src.shape[1]), dtype=torch.bfloat16, device=src.device)
+    lib = _lib.load()
+    with torch.cuda.device(src.device):
+        rc = lib.moe_gather_rows_fwd(src.data_ptr(), gather.data_ptr(), gather_shift, n_rows_dev.data_ptr(),
+                                     max_rows, src.shape[1], dst.data_ptr(), _stream_ptr(src))
+    _lib.check(rc, "moe_gather_rows_fwd")
+    return dst
+
+
+def combine(y: Tensor, r: Routing, S: int, M: int) -> Tensor:
+    """out[s] = sum_j bf16(w[s,j]) * y[pos(s,j)]  (the ``sec,ecm->sm`` einsum)."""
+    _need(y, "y", torch.bfloat16, 2)
+    if y.shape[1] != M or y.shape[0] < r.max_rows:
+        raise ValueError(f"y {tuple(y.shape)} too small for max_rows={r.max_rows}, M={M}")
+    if r.expert_idx.shape[0] != S:
+        raise ValueError("routing does not match S")
+    out = torch.empty((S, M), dtype=torch.bfloat16, device=y.device)
+    lib = _lib.load()
+    with torch.cuda.device(y.device):
+        rc = lib.moe_combine_fwd(y.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(), r.weight.data_ptr(),
+                                 r.expert_offsets.data_ptr(), S, M, r.expert_idx.shape[1], out.data_ptr(),
+                                 _stream_ptr(y))
+    _lib.check(rc, "moe_combine_fwd")
+    return out

@@ -176,9 +176,14 @@ class TopKGateRef(nn.Module):
         self.noise: Optional[Tensor] = None
         self.rts_uniform: Optional[Tensor] = None
         self.last_logits: Optional[Tensor] = None
+        #: oracle-only: use these fp32 logits instead of the CPU GEMV ("given fp32 gate logits" parity contract)
+        self.logits_override: Optional[Tensor] = None
 
     def forward(self, x: Tensor, used_token: Optional[Tensor] = None):
         logits = F.linear(x.float(), self.wg.weight.float())
+        if self.logits_override is not None:
+            assert self.logits_override.shape == logits.shape
+            logits = self.logits_override.clone()
         self.last_logits = logits.detach()
         cf = self.capacity_factor if self.training else self.eval_capacity_factor
         if self.k == 1:

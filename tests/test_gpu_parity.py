@@ -1,0 +1,362 @@
+"""GPU parity tests: the HIP path (through the C ABI, via moe_llava_amd.ops / MoE) against the CPU oracle.
+
+Bars (BASELINE.json north_star): expert ids, slots, drops, exp_counts, kept_counts, offsets, perm BIT-EXACT given
+fp32 logits and lowest-index tie-break; l_aux within 1e-5; outputs within bf16 tolerance rtol 1e-2 (max-abs
+printed).  The oracle is "parity unpinned" against upstream DeepSpeed (see oracle/__init__.py).
+"""
+import pytest
+import torch
+
+from oracle import ds_moe_index as ix
+from oracle import ds_moe_literal as lit
+from oracle.expert_mlps import PhiMLPRef, QWenMLPRef, StableLMMLPRef
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from moe_llava_amd import ops
+    return ops
+
+
+def _check_routing(logits_cpu, C, noise_cpu=None, drop=True):
+    ops = _ops()
+    S, E = logits_cpu.shape
+    ref = ix.route_top2(logits_cpu.clone(), C, noise_cpu, drop)
+    r = ops.routing_top2(logits_cpu.to(DEV), C, None if noise_cpu is None else noise_cpu.to(DEV), drop)
+    torch.cuda.synchronize()
+    assert torch.equal(r.expert_idx.cpu(), ref["expert_idx"]), "expert ids differ"
+    assert torch.equal(r.slot.cpu(), ref["slot"]), "slots / drops differ"
+    assert torch.equal(r.exp_counts.cpu(), ref["exp_counts"]), "exp_counts differ"
+    assert torch.equal(r.kept_counts.cpu(), ref["kept_counts"]), "kept_counts differ"
+    offs, perm = ix.dispatch_order(ref, E)
+    assert torch.equal(r.expert_offsets.cpu(), offs)
+    n = int(offs[-1])
+    assert n <= r.max_rows
+    assert torch.equal(r.perm.cpu()[:n], perm)
+    # weights: fp32, a few ulp (device expf vs host expf); exactly 1.0 where one choice survives
+    assert torch.allclose(r.weight.cpu(), ref["weight"], atol=1e-6, rtol=0)
+    one = (ref["slot"] >= 0).sum(1) == 1
+    if one.any():
+        assert torch.equal(r.weight.cpu()[one].max(1)[0], torch.ones(int(one.sum())))
+    assert abs(float(r.l_aux) - float(ref["l_aux"])) <= 1e-5
+    return r, ref
+
+
+def test_routing_known_answer():
+    logits = torch.tensor([[3., 2., 1.], [3., 1., 2.], [2., 3., 1.], [3., 2., 1.]])
+    r, _ = _check_routing(logits, 2)
+    assert r.exp_counts.tolist() == [4, 3, 1]
+    assert r.slot.tolist() == [[0, 1], [1, 0], [0, -1], [-1, -1]]
+    assert abs(float(r.l_aux) - 1.4936405) < 1e-5
+    w = r.weight.cpu()
+    assert float(w[2, 0]) == 1.0 and float(w[2, 1]) == 0.0 and float(w[3].abs().sum()) == 0.0
+    assert abs(float(w[0, 0]) - 0.731059) < 2e-6 and abs(float(w[0, 1]) - 0.268941) < 2e-6
+
+
+@pytest.mark.parametrize("S,E,cf,seed", [
+    (1, 4, 2.0, 0), (2, 2, 1.0, 1), (63, 4, 1.5, 2), (64, 4, 1.5, 3), (255, 4, 1.0, 4), (256, 8, 1.5, 5),
+    (257, 4, 0.5, 6), (704, 4, 1.5, 7), (2432, 4, 1.5, 8), (5000, 3, 0.75, 9), (22528, 4, 1.5, 10),
+    (4099, 16, 1.25, 11), (3000, 64, 1.0, 12), (131072, 8, 1.0, 13)])
+@pytest.mark.parametrize("noisy", [False, True])
+def test_routing_bit_exact(S, E, cf, seed, noisy):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(S, E, generator=g)
+    if seed % 2 == 1 and S > 8:                # capacity-drop stress: expert 0 overflows
+        logits[: S // 2, 0] += 2.0
+    noise = lit.gumbel_noise((S, E), 99) if noisy else None
+    C = lit.capacity_of(S, E, cf * 2, 0)
+    _check_routing(logits, C, noise)
+
+
+def test_routing_no_drop_and_min_capacity():
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(777, 4, generator=g)
+    logits[:, 1] += 1.5
+    _check_routing(logits, 0, None, drop=False)
+    _check_routing(logits, lit.capacity_of(777, 4, 0.1, 300), None)       # min_capacity wins
+
+
+def test_routing_ties_and_extremes():
+    S, E = 300, 4
+    _check_routing(torch.zeros(S, E), lit.capacity_of(S, E, 3.0, 0))      # all equal: experts 0 then 1
+    lg = torch.zeros(S, E)
+    lg[:, 2] = 5.0
+    lg[:, 1] = 1.0
+    _check_routing(lg, lit.capacity_of(S, E, 3.0, 0))                      # everything to experts 2 and 1
+    lg = torch.randn(S, E, generator=torch.Generator().manual_seed(1)).round()   # many exact ties
+    _check_routing(lg, lit.capacity_of(S, E, 2.0, 0))
+    lg = torch.randn(S, E, generator=torch.Generator().manual_seed(2)) * 60.0    # gates underflow to 0
+    _check_routing(lg, lit.capacity_of(S, E, 3.0, 0))
+
+
+def test_capacity_host_formula_matches_oracle():
+    from moe_llava_amd.sharded_moe import capacity_of
+    for S in (1, 3, 5, 7, 704, 705, 2432, 22528, 54848, 131072):
+        for E in (2, 3, 4, 8, 64):
+            for cf in (0.25, 0.5, 1.0, 1.1, 1.25, 1.5, 2.0, 3.3):
+                for mc in (0, 4, 16):
+                    assert capacity_of(S, E, cf * 2, mc) == lit.capacity_of(S, E, cf * 2, mc), (S, E, cf, mc)
+
+
+@pytest.mark.parametrize("wg_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S,M,E", [(1, 64, 4), (37, 2048, 4), (704, 2048, 4), (513, 2560, 8), (100, 512, 16), (50, 256, 64)])
+def test_gate_logits_numerics(S, M, E, wg_dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(S + M + E)
+    x = torch.randn(S, M, generator=g).to(torch.bfloat16)
+    wg = (torch.randn(E, M, generator=g) * 0.02).to(wg_dtype)
+    got = ops.gate_logits(x.to(DEV), wg.to(DEV)).cpu()
+    ref = (x.double() @ wg.double().t())
+    tol = 1e-5 * float(ref.abs().max()) + 2e-6 * (M ** 0.5)
+    assert float((got.double() - ref).abs().max()) <= tol
+    # and against the fp32 torch op the reference uses
+    ref32 = torch.nn.functional.linear(x.float(), wg.float())
+    assert torch.allclose(got, ref32, atol=tol, rtol=0)
+
+
+def _mk_experts(kind, M, I, E, seed, scale=0.05):
+    g = torch.Generator().manual_seed(seed)
+    mk = {"stablelm": lambda: StableLMMLPRef(M, I), "phi": lambda: PhiMLPRef(M, I),
+          "qwen": lambda: QWenMLPRef(M, I), "qwen_bias": lambda: QWenMLPRef(M, I, bias=True)}[kind]
+    exps = []
+    for _ in range(E):
+        e = mk().to(torch.bfloat16)
+        for p in e.parameters():
+            p.data = (torch.randn(p.shape, generator=g) * scale).to(torch.bfloat16)
+        exps.append(e)
+    return exps
+
+
+def _build_pair(kind, M, I, E, S_shape, cf, seed, noisy=False, training=True):
+    """(oracle MoERef on CPU, product MoE on GPU) with identical parameters."""
+    import moe_llava_amd
+    exps = _mk_experts(kind, M, I, E, seed)
+    ref = lit.MoERef(M, exps[0], num_experts=E, k=2, capacity_factor=cf, eval_capacity_factor=2.0,
+                     min_capacity=0, top2_2nd_expert_sampling=noisy)
+    for dst, src in zip(ref.deepspeed_moe.experts.deepspeed_experts, exps):
+        dst.load_state_dict(src.state_dict())
+    g = torch.Generator().manual_seed(seed + 100)
+    ref.deepspeed_moe.gate.wg.weight.data = torch.randn(E, M, generator=g) * 0.1
+    mine = moe_llava_amd.MoE(M, exps[0], num_experts=E, k=2, capacity_factor=cf, eval_capacity_factor=2.0,
+                             min_capacity=0, top2_2nd_expert_sampling=noisy)
+    missing = mine.load_state_dict(ref.state_dict(), strict=True)      # checkpoint-key ABI
+    assert not missing.missing_keys and not missing.unexpected_keys
+    for m in mine.deepspeed_moe.experts.deepspeed_experts:
+        m.to(torch.bfloat16)
+    mine = mine.to(DEV)
+    ref.train(training)
+    mine.train(training)
+    x = torch.randn(*S_shape, M, generator=g).to(torch.bfloat16)
+    return ref, mine, x
+
+
+def _report(name, got, want):
+    d = (got.float() - want.float()).abs()
+    scale = float(want.float().abs().max())
+    print(f"[parity] {name}: max_abs={float(d.max()):.4e} ref_max={scale:.4e} "
+          f"max_rel_to_scale={float(d.max()) / max(scale, 1e-30):.3e}")
+    return float(d.max()), scale
+
+
+@pytest.mark.parametrize("kind,M,I,E,shape,cf", [
+    ("stablelm", 64, 128, 4, (2, 48), 1.0),
+    ("stablelm", 128, 320, 4, (3, 111), 1.5),
+    ("qwen", 128, 192, 4, (1, 300), 0.5),
+    ("qwen_bias", 64, 64, 2, (1, 70), 1.5),
+    ("phi", 128, 256, 4, (2, 130), 1.5),
+    ("phi", 64, 576, 8, (1, 257), 1.0),
+])
+@pytest.mark.parametrize("noisy", [False, True])
+def test_moe_layer_vs_literal_oracle(kind, M, I, E, shape, cf, noisy):
+    """Whole block against the dense-mask oracle, given the kernel's own fp32 logits (the parity contract)."""
+    ref, mine, x = _build_pair(kind, M, I, E, shape, cf, seed=7, noisy=noisy)
+    S = x.numel() // M
+    noise = lit.gumbel_noise((S, E), 99) if noisy else None
+    captured = {}
+    h = mine.deepspeed_moe.gate.wg.register_forward_hook(lambda m, i, o: captured.__setitem__("lg", o.detach().cpu()))
+    if noisy:
+        mine.deepspeed_moe.gate.noise_override = noise.to(DEV)
+        ref.deepspeed_moe.gate.noise = noise
+    with torch.no_grad():
+        out, l_aux, exp_counts = mine(x.to(DEV))
+    torch.cuda.synchronize()
+    h.remove()
+    assert isinstance(out, torch.Tensor) and out.shape == x.shape and out.dtype == torch.bfloat16
+    assert l_aux.dim() == 0 and l_aux.dtype == torch.float32
+    assert exp_counts.dtype == torch.int64 and exp_counts.shape == (E,)
+    lg = captured["lg"]
+    assert lg.shape == (S, E) and lg.dtype == torch.float32                # wg hook sees [S,E] fp32 logits
+    ref_lg = torch.nn.functional.linear(x.reshape(-1, M).float(), ref.deepspeed_moe.gate.wg.weight.float())
+    assert torch.allclose(lg, ref_lg, atol=1e-4, rtol=1e-4)
+    ref.deepspeed_moe.gate.logits_override = lg
+    with torch.no_grad():
+        r_out, r_laux, r_counts = ref(x)
+    assert torch.equal(exp_counts.cpu(), r_counts)
+    assert abs(float(l_aux) - float(r_laux)) <= 1e-5
+    err, scale = _report(f"{kind} M{M} I{I} E{E} S{S} noisy={noisy}", out.cpu(), r_out)
+    assert torch.allclose(out.cpu().float(), r_out.float(), rtol=1e-2, atol=1e-2 * scale)
+    # rows of tokens that lost both choices are exactly zero
+    slot = mine.deepspeed_moe.last_routing.slot.cpu()
+    dead = (slot < 0).all(1)
+    if dead.any():
+        assert float(out.cpu().reshape(-1, M)[dead].float().abs().max()) == 0.0
+
+
+def test_eval_mode_uses_eval_capacity_and_s1_decode():
+    ref, mine, x = _build_pair("stablelm", 64, 128, 4, (1, 1), 1.0, seed=3, training=False)
+    with torch.no_grad():
+        out, l_aux, cnt = mine(x.to(DEV))
+    lg = _ops().gate_logits(x.reshape(-1, 64).to(DEV), mine.deepspeed_moe.gate.wg.weight).cpu()
+    ref.deepspeed_moe.gate.logits_override = lg
+    with torch.no_grad():
+        r_out, r_laux, r_cnt = ref(x)
+    assert mine.deepspeed_moe.last_routing.capacity == lit.capacity_of(1, 4, 4.0, 0) == 1
+    assert torch.equal(cnt.cpu(), r_cnt)
+    _, scale = _report("decode S=1", out.cpu(), r_out)
+    assert torch.allclose(out.cpu().float(), r_out.float(), rtol=1e-2, atol=1e-2 * scale)
+
+
+@pytest.mark.parametrize("kind,M,I", [("stablelm", 2048, 5632), ("phi", 2560, 10240)])
+def test_cfg1_block_vs_index_oracle(kind, M, I):
+    """BASELINE config 1 shape (1 x (576 img + 128 text) tokens, 4 experts, top-2, cf 1.5) against the index-form
+    oracle on a sample of tokens (the CPU MLP over every row takes too long for the CPU suite budget)."""
+    E, S = 4, 704
+    ref, mine, x = _build_pair(kind, M, I, E, (1, S), 1.5, seed=11)
+    for e in ref.deepspeed_moe.experts.deepspeed_experts:          # keep activations O(1)
+        for p in e.parameters():
+            p.data = (p.data.float() * 0.4).to(torch.bfloat16)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV)
+    with torch.no_grad():
+        out, l_aux, cnt = mine(x.to(DEV))
+    torch.cuda.synchronize()
+    lg = _ops().gate_logits(x.reshape(-1, M).to(DEV), mine.deepspeed_moe.gate.wg.weight).cpu()
+    C = lit.capacity_of(S, E, 3.0, 0)
+    assert C == 528
+    r = ix.route_top2(lg, C)
+    assert torch.equal(cnt.cpu(), r["exp_counts"])
+    assert torch.equal(mine.deepspeed_moe.last_routing.slot.cpu(), r["slot"])
+    sample = torch.randperm(S, generator=torch.Generator().manual_seed(0))[:96]
+    sub = {k: (v[sample] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == S else v) for k, v in r.items()}
+    with torch.no_grad():
+        want = ix.moe_forward_index(x.reshape(-1, M)[sample], sub, list(ref.deepspeed_moe.experts.deepspeed_experts))
+    got = out.cpu().reshape(-1, M)[sample]
+    err, scale = _report(f"cfg1 {kind}", got, want)
+    assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-2 * scale)
+
+
+def test_full_size_properties_cfg2():
+    """BASELINE config 2 size (batch 32 -> S = 22 528): size-independent properties instead of a full CPU run."""
+    import moe_llava_amd
+    from moe_llava_amd.expert_mlps import StableLMMLP
+    M, I, E, B, T = 2048, 5632, 4, 32, 704
+    torch.manual_seed(0)
+    moe = moe_llava_amd.MoE(M, StableLMMLP(M, I), num_experts=E, k=2, capacity_factor=1.5,
+                            eval_capacity_factor=2.0, min_capacity=0, top2_2nd_expert_sampling=False)
+    moe = moe.to(torch.bfloat16)
+    for p in moe.deepspeed_moe.experts.parameters():
+        p.data.normal_(0, 0.02)
+    moe.deepspeed_moe.gate.wg.weight.data.normal_(0, 0.2)
+    moe = moe.to(DEV).train()
+    x = torch.randn(B, T, M, device=DEV).to(torch.bfloat16)
+    x[:, :576] += 0.5                                  # "image" rows skew the router (drops happen)
+    with torch.no_grad():
+        out1, l1, c1 = moe(x)
+        r = moe.deepspeed_moe.last_routing
+        out2, l2, c2 = moe(x)
+    torch.cuda.synchronize()
+    S = B * T
+    assert torch.equal(out1, out2) and torch.equal(c1, c2) and float(l1) == float(l2)        # deterministic
+    assert int(c1.sum()) == 2 * S
+    C = lit.capacity_of(S, E, 3.0, 0)
+    assert r.capacity == C == 16896
+    kept = r.kept_counts.cpu()
+    assert int(kept.max()) <= C
+    offs = r.expert_offsets.cpu()
+    n = int(offs[-1])
+    perm = r.perm.cpu()[:n].long()
+    assert perm.unique().numel() == n                                   # each (token, choice) at most once
+    slot, idx = r.slot.cpu().long(), r.expert_idx.cpu().long()
+    tok, ch = perm // 2, perm % 2
+    pos = torch.arange(n)
+    assert torch.equal(offs[idx[tok, ch]].long() + slot[tok, ch], pos)  # perm is the inverse of (expert, slot)
+    assert int((slot >= 0).sum()) == n
+    # routing equals the index-form oracle given the kernel's logits
+    lg = _ops().gate_logits(x.reshape(-1, M), moe.deepspeed_moe.gate.wg.weight).cpu()
+    ref = ix.route_top2(lg, C)
+    assert torch.equal(slot.int(), ref["slot"]) and torch.equal(idx.int(), ref["expert_idx"])
+    assert abs(float(l1) - float(ref["l_aux"])) <= 1e-5
+    dead = (slot < 0).all(1)
+    o = out1.reshape(-1, M)
+    if dead.any():
+        assert float(o[dead.to(DEV)].float().abs().max()) == 0.0
+    # sampled rows against the oracle MLPs
+    sample = torch.randperm(S, generator=torch.Generator().manual_seed(1))[:48]
+    sub = {k: (v[sample] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == S else v) for k, v in ref.items()}
+    cpu_experts = [StableLMMLPRef(M, I).to(torch.bfloat16) for _ in range(E)]
+    for ce, ge in zip(cpu_experts, moe.deepspeed_moe.experts.deepspeed_experts):
+        ce.load_state_dict({k: v.cpu() for k, v in ge.state_dict().items()})
+    with torch.no_grad():
+        want = ix.moe_forward_index(x.reshape(-1, M)[sample.to(DEV)].cpu(), sub, cpu_experts)
+    got = o[sample.to(DEV)].cpu()
+    err, scale = _report("cfg2 sampled rows", got, want)
+    assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-2 * scale)
+
+
+def test_experts_forward_reference_layout():
+    """Experts.forward([ep, E_local, C, M]) (upstream layout) equals the per-expert oracle MLPs."""
+    import moe_llava_amd
+    M, I, El, C = 64, 128, 3, 37
+    exps = _mk_experts("stablelm", M, I, El, seed=5)
+    ex = moe_llava_amd.Experts(exps[0], El, "ep_size_1")
+    for d, s in zip(ex.deepspeed_experts, exps):
+        d.load_state_dict(s.state_dict())
+    ex = ex.to(DEV)
+    x = torch.randn(2, El, C, M, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16)
+    y = ex(x.to(DEV)).cpu()
+    with torch.no_grad():
+        want = torch.cat([exps[i](x[:, i:i + 1]) for i in range(El)], dim=1)
+    err, scale = _report("Experts.forward", y, want)
+    assert torch.allclose(y.float(), want.float(), rtol=1e-2, atol=1e-2 * scale)
+    for p in ex.parameters():
+        assert p.allreduce is False and p.group_name == "ep_size_1"
+
+
+def test_state_dict_views_survive_load_and_inplace_update():
+    """Expert params are views of the packed buffers: load_state_dict / in-place updates are seen by the kernel."""
+    ref, mine, x = _build_pair("stablelm", 64, 128, 4, (1, 64), 2.0, seed=21)
+    with torch.no_grad():
+        o1, _, _ = mine(x.to(DEV))
+        sd = {k: v.clone() for k, v in mine.state_dict().items()}
+        for k in sd:
+            if "down_proj" in k:
+                sd[k] = sd[k] * 2
+        mine.load_state_dict(sd)
+        o2, _, _ = mine(x.to(DEV))
+        for e in mine.deepspeed_moe.experts.deepspeed_experts:
+            e.down_proj.weight.mul_(0.5)
+        o3, _, _ = mine(x.to(DEV))
+    assert torch.allclose(o2.float(), 2 * o1.float(), rtol=2e-2, atol=1e-3)
+    assert torch.equal(o3, o1)
+
+
+def test_errors_are_loud():
+    import moe_llava_amd
+    from moe_llava_amd._lib import MoEKernelError
+    from moe_llava_amd.expert_mlps import StableLMMLP
+    ops = _ops()
+    with pytest.raises(MoEKernelError):
+        ops.gate_logits(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64))       # CPU tensor
+    with pytest.raises(TypeError):
+        ops.gate_logits(torch.zeros(4, 64, device=DEV), torch.zeros(4, 64, device=DEV))     # fp32 activations
+    with pytest.raises(MoEKernelError):
+        ops.gate_logits(torch.zeros(4, 60, dtype=torch.bfloat16, device=DEV), torch.zeros(4, 60, device=DEV))  # M%8
+    moe = moe_llava_amd.MoE(64, StableLMMLP(64, 128), num_experts=4, k=2).to(DEV)           # fp32 experts
+    with pytest.raises(TypeError):
+        moe(torch.zeros(1, 8, 64, dtype=torch.bfloat16, device=DEV))
+    with pytest.raises(NotImplementedError):
+        moe_llava_amd.MoE(64, torch.nn.Linear(64, 64), num_experts=2, k=2).to(torch.bfloat16).to(DEV)(
+            torch.zeros(1, 8, 64, dtype=torch.bfloat16, device=DEV))
