@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""MoE-layer throughput bench (BASELINE.json metric: MoE-layer tokens/s on MI355X, top-2, 4 experts).
+
+A "step" is one forward of the sparse-MoE FFN block (gate -> top-2 routing with capacity drop -> grouped expert
+FFN -> weighted combine) over one synthetic batch that is already resident in HBM.
+
+  N = 1 : BASELINE config 2 -- MoE-LLaVA-StableLM-1.6B-4e block (d=2048, expert width 5632 SwiGLU, 4 experts,
+          top-2, capacity factor 1.5, training-mode capacity), batch 32 x (576 image + 128 text) tokens, bf16.
+  N > 1 : the same block and per-GPU batch on every rank (weak scaling); the 4 experts shard expert-parallel
+          over min(N, 4) consecutive ranks (x N/4 replicas), token dispatch / combine by RCCL all-to-all.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel (the
+fc1 grouped GEMM, timed with HIP events inside the timed region) and `cpu_baseline` (the literal dense-mask
+oracle of the reference layer on the host cores, on one 704-token sample = BASELINE config 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+M, I, E, TOPK, CF = 2048, 5632, 4, 2, 1.5
+N_IMG, N_TXT, BATCH = 576, 128, 32
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def make_inputs(batch: int, device, seed: int):
+    """text rows ~ N(0,1); image rows N(0,1) + 0.5*u_img (one fixed unit direction, gives the
+    modality-skewed routing); bf16."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(batch, N_IMG + N_TXT, M, generator=g)
+    u = torch.randn(M, generator=torch.Generator().manual_seed(4321))
+    u = u / u.norm() * (M ** 0.5)
+    x[:, :N_IMG] += 0.5 * u
+    return x.to(torch.bfloat16).to(device)
+
+
+def build_block(device, ep_size: int, seed: int = 1234):
+    import moe_llava_amd
+    from moe_llava_amd.expert_mlps import StableLMMLP
+    torch.manual_seed(seed)
+    proto = StableLMMLP(M, I).to(torch.bfloat16)
+    # the nine kwargs of the reference's constructor call (llava_stablelm_moe.py:550-560, finetune_moe.sh:3-13)
+    moe = moe_llava_amd.MoE(M, expert=proto, num_experts=E, ep_size=ep_size, k=TOPK, capacity_factor=CF,
+                            eval_capacity_factor=2.0, min_capacity=0, use_residual=False)
+    g = torch.Generator().manual_seed(seed)
+    state = {"wg": torch.randn(E, M, generator=g) * 0.02}
+    experts = []
+    for e in range(E):
+        experts.append({n: (torch.randn(shape, generator=g) * 0.02).to(torch.bfloat16)
+                        for n, shape in (("gate_proj", (I, M)), ("up_proj", (I, M)), ("down_proj", (M, I)))})
+    return moe, state, experts
+
+
+def load_weights(moe, state, experts, device, ep_rank: int):
+    el = moe.num_local_experts
+    moe.deepspeed_moe.gate.wg.weight.data = state["wg"].clone()
+    for le, mod in enumerate(moe.deepspeed_moe.experts.deepspeed_experts):
+        w = experts[ep_rank * el + le]
+        mod.gate_proj.weight.data = w["gate_proj"].clone()
+        mod.up_proj.weight.data = w["up_proj"].clone()
+        mod.down_proj.weight.data = w["down_proj"].clone()
+    return moe.to(device).train()
+
+
+def cpu_baseline(state, experts, budget_s: float = 25.0):
+    """Literal dense-mask restatement of the reference layer (oracle) on the host cores, one 704-token sample
+    (BASELINE config 1: S=704, C=528).  Checker code timed as a reported baseline, never shipped."""
+    from oracle import ds_moe_literal as lit
+    from oracle.expert_mlps import StableLMMLPRef
+    torch.manual_seed(0)
+    ref = lit.MoERef(M, StableLMMLPRef(M, I).to(torch.bfloat16), num_experts=E, ep_size=1, k=TOPK,
+                     capacity_factor=CF, eval_capacity_factor=2.0, min_capacity=0, use_residual=False)
+    ref.deepspeed_moe.gate.wg.weight.data = state["wg"].clone()
+    for e, mod in enumerate(ref.deepspeed_moe.experts.deepspeed_experts):
+        mod.gate_proj.weight.data = experts[e]["gate_proj"].clone()
+        mod.up_proj.weight.data = experts[e]["up_proj"].clone()
+        mod.down_proj.weight.data = experts[e]["down_proj"].clone()
+    ref.train()
+    x = make_inputs(1, "cpu", seed=1234)
+    S = x.shape[0] * x.shape[1]
+    ref.deepspeed_moe.gate.noise = lit.gumbel_noise((S, E), 99)    # upstream default: 2nd-expert sampling on
+    times = []
+    t_all = time.perf_counter()
+    with torch.no_grad():
+        for it in range(4):
+            t0 = time.perf_counter()
+            ref(x)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > budget_s:
+                break
+    timed = times[1:] if len(times) > 1 else times          # first run is the warm-up when there is room for more
+    t = statistics.median(timed)
+    return {"value": S / t, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"literal dense-mask oracle (restated deepspeed MoE, torch CPU bf16), 1 x ({N_IMG}+{N_TXT}) tokens "
+                      f"= BASELINE config 1 (S={S}, C=528), {len(timed)} timed run(s) after "
+                      f"{len(times) - len(timed)} warm-up, median {t:.3f} s",
+            "seconds": t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (704 tokens each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    import torch.distributed as dist
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    ep = min(world, E)
+    while E % ep or world % ep:
+        ep -= 1
+    ep_rank = rank % ep
+    moe, state, experts = build_block(device, ep)
+    moe = load_weights(moe, state, experts, device, ep_rank)
+    if ep > 1:
+        moe.set_deepspeed_parallelism()
+    x = make_inputs(args.batch, device, seed=1234 + rank)
+    S = x.shape[0] * x.shape[1]
+
+    from moe_llava_amd import ops
+    timer = ops.PhaseTimer()
+
+    def step():
+        with torch.no_grad():
+            return moe(x)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    moe.deepspeed_moe.timer = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, l_aux, exp_counts = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    moe.deepspeed_moe.timer = None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    # ---- roofline of the dominant kernel (fc1 grouped GEMM), HIP-event timed inside the timed region ----
+    fc1_ms = timer.durations("fc1_begin", "fc1_end")
+    fc2_ms = timer.durations("fc1_end", "fc2_end")
+    gate_ms = timer.durations("gate_begin", "gate_end")
+    r = moe.deepspeed_moe.last_routing
+    rows_local = None
+    if ep == 1:
+        rows_local = int(r.expert_offsets[-1])               # kept (token, expert) pairs = GEMM rows this launch
+    fc1_avg = statistics.mean(fc1_ms) if fc1_ms else None
+    roofline = None
+    if fc1_avg and rows_local is not None:
+        flops = 2.0 * rows_local * (2 * I) * M                # algorithmic: gate+up projections over kept rows only
+        ach = flops / (fc1_avg * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "grouped_gemm_kernel<SWIGLU> (fc1 + SiLU*mul epilogue)",
+                    "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                    "traffic": None, "avg_launch_ms": fc1_avg, "rows": rows_local,
+                    "fc2_avg_launch_ms": statistics.mean(fc2_ms) if fc2_ms else None,
+                    "fc2_tflops": (2.0 * rows_local * M * I / (statistics.mean(fc2_ms) * 1e-3) / 1e12) if fc2_ms else None,
+                    "gate_routing_avg_ms": statistics.mean(gate_ms) if gate_ms else None}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(state, experts)
+        ms = elapsed / args.steps * 1e3
+        n_kept = (rows_local / S) if rows_local is not None else None
+        line = {
+            "metric": "MoE-layer tokens/sec (top-2, 4 experts, StableLM-1.6B-4e block)",
+            "value": world * S * args.steps / elapsed,
+            "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 2: StableLM-1.6B-4e MoE block forward, d={M}, expert width {I} SwiGLU, "
+                                   f"{E} experts top-{TOPK}, capacity factor {CF} (training capacity), 2nd-expert Gumbel "
+                                   f"sampling on (upstream default), {args.batch} x ({N_IMG} img + {N_TXT} text) tokens per GPU",
+                       "tokens_per_gpu": S, "global_tokens": world * S,
+                       "parallelism": "single GPU" if world == 1 else f"ep{ep} x dp{world // ep} (RCCL all-to-all)",
+                       "kept_pairs_per_token": n_kept},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "layer_tflops": (n_kept * 6.0 * M * I * S / (ms * 1e-3) / 1e12) if n_kept else None,
+            "l_aux": float(l_aux), "exp_counts": exp_counts.tolist(),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

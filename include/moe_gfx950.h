@@ -108,6 +108,21 @@ int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gathe
                        const int32_t *group_offsets, int G, int n_experts_local, int max_rows,
                        int M, int I, void *h_ws, void *y, void *stream);
 
+/* epilogues of moe_grouped_gemm_fwd */
+#define MOE_EPI_PLAIN    0 /* out = bf16(acc + bias)                                  (fc2 / down_proj / c_proj) */
+#define MOE_EPI_SWIGLU   1 /* W = [Wa ; Wb] ([2N, K]); out = silu(bf16(Wa x)) * bf16(Wb x), N output columns     */
+#define MOE_EPI_GELU_NEW 2 /* out = gelu_new(bf16(acc + bias))                                                   */
+
+/* moe_grouped_gemm_fwd: ONE grouped GEMM launch, the primitive moe_expert_ffn_fwd is made of (it lets a caller
+ * time or schedule fc1 and fc2 separately).  out[p, 0:N] = epilogue( A[p, 0:K] @ W_e[.., K]^T ) for every compact
+ * row p of group g (expert e = g % n_experts_local).  Same per-expert nn.Linear semantics as above
+ * (stablelm/modeling_stablelm_epoch.py:167-168, phi/modeling_phi.py:211-215, qwen/modeling_qwen.py:601-606).
+ *   w    [n_experts_local, N (or 2N for SWIGLU), K] bf16;  bias [n_experts_local, N (or 2N)] bf16 or NULL
+ * K % 64 == 0, N % 4 == 0, lda >= K, ldo >= N.  One launch. */
+int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
+                         const void *w, const void *bias, const int32_t *group_offsets, int G,
+                         int n_experts_local, int max_rows, int K, int N, void *out, int64_t ldo, void *stream);
+
 /* moe_gather_rows_fwd: dst[p] = src[gather[p] >> gather_shift] for p < *n_rows_dev (device int32),
  * rows of M bf16.  Builds the expert-sorted send buffer of the expert-parallel all-to-all
  * (replaces the dispatch einsum in front of _AllToAll). */

@@ -27,6 +27,9 @@ _SIGNATURES = [
     ("moe_expert_ffn_fwd", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    ("moe_grouped_gemm_fwd", c_int,
+     [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+      c_void_p, c_int64, c_void_p]),
     ("moe_gather_rows_fwd", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("moe_combine_fwd", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -29,7 +29,7 @@ constexpr int BK = 64;
 constexpr int NTHREADS = 512;
 constexpr int RS = 4;  // row tiles per super-row (L2 reuse of the W panel inside an XCD)
 
-enum { EPI_PLAIN = 0, EPI_SWIGLU = 1, EPI_GELU_NEW = 2 };
+enum { EPI_PLAIN = MOE_EPI_PLAIN, EPI_SWIGLU = MOE_EPI_SWIGLU, EPI_GELU_NEW = MOE_EPI_GELU_NEW };
 
 struct GemmParams {
     const bf16_t *a;
@@ -271,71 +271,72 @@ static int launch_gemm(const GemmParams &p, hipStream_t st) {
 
 using namespace moe;
 
+static int gemm_args_ok(const char *fn, const void *a, int64_t lda, int gather_shift, const void *w, const int32_t *group_offsets,
+                        int G, int n_experts_local, int max_rows, int K, int N, const void *out, int64_t ldo) {
+    if (!a || !w || !group_offsets || !out) return fail(MOE_ERR_ARG, "%s: null pointer", fn);
+    if (K <= 0 || N <= 0 || (K % BK) || (N & 3) || G < 1 || G > 4096 || n_experts_local < 1 || max_rows < 0 ||
+        gather_shift < 0 || gather_shift > 1 || lda < K || (lda & 7) || ldo < N || (ldo & 3))
+        return fail(MOE_ERR_SHAPE,
+                    "%s: need K%%64==0, N%%4==0, 1<=G<=4096, lda>=K, lda%%8==0, ldo>=N, ldo%%4==0 (K=%d N=%d G=%d lda=%lld ldo=%lld)",
+                    fn, K, N, G, (long long)lda, (long long)ldo);
+    if (!aligned16(a) || !aligned16(w) || !aligned16(out)) return fail(MOE_ERR_ALIGN, "%s: pointers must be 16-byte aligned", fn);
+    return 0;
+}
+
+extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
+                                    const void *w, const void *bias, const int32_t *group_offsets, int G,
+                                    int n_experts_local, int max_rows, int K, int N, void *out, int64_t ldo,
+                                    void *stream) {
+    if (epilogue != MOE_EPI_PLAIN && epilogue != MOE_EPI_SWIGLU && epilogue != MOE_EPI_GELU_NEW)
+        return fail(MOE_ERR_ARG, "moe_grouped_gemm_fwd: unknown epilogue %d", epilogue);
+    int rc = gemm_args_ok("moe_grouped_gemm_fwd", a, lda, gather_shift, w, group_offsets, G, n_experts_local, max_rows, K, N,
+                          out, ldo);
+    if (rc) return rc;
+    if (max_rows == 0) return 0;
+    GemmParams p;
+    p.a = (const bf16_t *)a;
+    p.lda = lda;
+    p.gather = gather;
+    p.gather_shift = gather_shift;
+    p.w = (const bf16_t *)w;
+    p.bias = (const bf16_t *)bias;
+    p.group_offsets = group_offsets;
+    p.G = G;
+    p.n_experts = n_experts_local;
+    p.out = (bf16_t *)out;
+    p.ldo = ldo;
+    p.K = K;
+    p.N_out = N;
+    p.b_row_offset = N;
+    p.max_row_tiles = max_rows / BM + G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
+    hipStream_t st = (hipStream_t)stream;
+    if (epilogue == MOE_EPI_SWIGLU) {
+        p.w_expert_stride = 2ll * N * K;
+        p.bias_expert_stride = 2ll * N;
+        p.col_tiles = (N + BNW / 2 - 1) / (BNW / 2);
+        return launch_gemm<EPI_SWIGLU>(p, st);
+    }
+    p.w_expert_stride = (long long)N * K;
+    p.bias_expert_stride = N;
+    p.col_tiles = (N + BNW - 1) / BNW;
+    if (epilogue == MOE_EPI_GELU_NEW) return launch_gemm<EPI_GELU_NEW>(p, st);
+    return launch_gemm<EPI_PLAIN>(p, st);
+}
+
 extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                   const void *w1, const void *b1, const void *w2, const void *b2,
                                   const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
                                   void *h_ws, void *y, void *stream) {
-    if (!a || !w1 || !w2 || !group_offsets || !h_ws || !y) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: null pointer");
+    if (!h_ws || !y || !w2) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: null pointer");
     if (act != MOE_ACT_SWIGLU && act != MOE_ACT_GELU_NEW) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: unknown act %d", act);
-    if (M <= 0 || I <= 0 || (M % BK) || (I % BK) || G < 1 || G > 4096 || n_experts_local < 1 || max_rows < 0 ||
-        gather_shift < 0 || gather_shift > 1 || lda < M || (lda & 7))
-        return fail(MOE_ERR_SHAPE,
-                    "moe_expert_ffn_fwd: need M%%64==0, I%%64==0, 1<=G<=4096, lda>=M, lda%%8==0 (M=%d I=%d G=%d lda=%lld)", M,
-                    I, G, (long long)lda);
-    if (!aligned16(a) || !aligned16(w1) || !aligned16(w2) || !aligned16(h_ws) || !aligned16(y))
-        return fail(MOE_ERR_ALIGN, "moe_expert_ffn_fwd: pointers must be 16-byte aligned");
-    if (max_rows == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    const int max_row_tiles = max_rows / BM + G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
-
-    GemmParams p1;
-    p1.a = (const bf16_t *)a;
-    p1.lda = lda;
-    p1.gather = gather;
-    p1.gather_shift = gather_shift;
-    p1.w = (const bf16_t *)w1;
-    p1.bias = (const bf16_t *)b1;
-    p1.group_offsets = group_offsets;
-    p1.G = G;
-    p1.n_experts = n_experts_local;
-    p1.out = (bf16_t *)h_ws;
-    p1.ldo = I;
-    p1.K = M;
-    p1.N_out = I;
-    p1.b_row_offset = I;
-    p1.max_row_tiles = max_row_tiles;
-    int rc;
-    if (act == MOE_ACT_SWIGLU) {
-        p1.w_expert_stride = 2ll * I * M;
-        p1.bias_expert_stride = 2ll * I;
-        p1.col_tiles = (I + BNW / 2 - 1) / (BNW / 2);
-        rc = launch_gemm<EPI_SWIGLU>(p1, st);
-    } else {
-        p1.w_expert_stride = (long long)I * M;
-        p1.bias_expert_stride = I;
-        p1.col_tiles = (I + BNW - 1) / BNW;
-        rc = launch_gemm<EPI_GELU_NEW>(p1, st);
-    }
+    if (M <= 0 || I <= 0 || (M % BK) || (I % BK))
+        return fail(MOE_ERR_SHAPE, "moe_expert_ffn_fwd: need M%%64==0 and I%%64==0 (M=%d I=%d)", M, I);
+    // validate the second GEMM before launching the first, so a bad call launches nothing
+    int rc = gemm_args_ok("moe_expert_ffn_fwd", h_ws, I, 0, w2, group_offsets, G, n_experts_local, max_rows, I, M, y, M);
     if (rc) return rc;
-
-    GemmParams p2;
-    p2.a = (const bf16_t *)h_ws;
-    p2.lda = I;
-    p2.gather = nullptr;
-    p2.gather_shift = 0;
-    p2.w = (const bf16_t *)w2;
-    p2.w_expert_stride = (long long)M * I;
-    p2.bias = (const bf16_t *)b2;
-    p2.bias_expert_stride = M;
-    p2.group_offsets = group_offsets;
-    p2.G = G;
-    p2.n_experts = n_experts_local;
-    p2.out = (bf16_t *)y;
-    p2.ldo = M;
-    p2.K = I;
-    p2.N_out = M;
-    p2.b_row_offset = 0;
-    p2.max_row_tiles = max_row_tiles;
-    p2.col_tiles = (M + BNW - 1) / BNW;
-    return launch_gemm<EPI_PLAIN>(p2, st);
+    rc = moe_grouped_gemm_fwd(act == MOE_ACT_SWIGLU ? MOE_EPI_SWIGLU : MOE_EPI_GELU_NEW, a, lda, gather, gather_shift, w1, b1,
+                              group_offsets, G, n_experts_local, max_rows, M, I, h_ws, I, stream);
+    if (rc) return rc;
+    return moe_grouped_gemm_fwd(MOE_EPI_PLAIN, h_ws, I, nullptr, 0, w2, b2, group_offsets, G, n_experts_local, max_rows, I, M,
+                                y, M, stream);
 }

@@ -15,6 +15,38 @@ from . import _lib
 
 ACT_SWIGLU = 0
 ACT_GELU_NEW = 1
+EPI_PLAIN, EPI_SWIGLU, EPI_GELU_NEW = 0, 1, 2
+
+
+class PhaseTimer:
+    """HIP-event marks on the stream the kernels are launched on (torch's current stream), in the spirit of
+    upstream MOELayer's ``wall_clock_breakdown`` timers.  ``durations()`` synchronises and returns, per pair of
+    consecutive marks of one forward, the list of elapsed milliseconds."""
+
+    def __init__(self):
+        self.events = []   # list of (name, event) in record order
+        self.enabled = True
+
+    def mark(self, name: str) -> None:
+        if not self.enabled:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.events.append((name, ev))
+
+    def reset(self) -> None:
+        self.events = []
+
+    def durations(self, begin: str, end: str):
+        torch.cuda.synchronize()
+        out, start = [], None
+        for name, ev in self.events:
+            if name == begin:
+                start = ev
+            elif name == end and start is not None:
+                out.append(start.elapsed_time(ev))
+                start = None
+        return out
 
 
 def _stream_ptr(t: Tensor) -> int:
@@ -105,7 +137,7 @@ def routing_top2(logits: Tensor, capacity: int, noise: Optional[Tensor] = None,
 
 def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
                w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
-               group_offsets: Tensor, max_rows: int) -> Tensor:
+               group_offsets: Tensor, max_rows: int, timer: Optional["PhaseTimer"] = None) -> Tensor:
     """Grouped expert MLP over compact rows; returns y [max_rows, M] bf16 (rows past the device-side
     group_offsets[G] are left unwritten)."""
     _need(a, "a", torch.bfloat16, 2)
@@ -140,13 +172,29 @@ def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
         return y
     h = torch.empty((max_rows, I), dtype=torch.bfloat16, device=dev)
     lib = _lib.load()
+    gp = gather.data_ptr() if gather is not None else None
+    b1p = b1.data_ptr() if b1 is not None else None
+    b2p = b2.data_ptr() if b2 is not None else None
     with torch.cuda.device(dev):
-        rc = lib.moe_expert_ffn_fwd(act, a.data_ptr(), a.stride(0), gather.data_ptr() if gather is not None else None,
-                                    gather_shift, w1.data_ptr(), b1.data_ptr() if b1 is not None else None,
-                                    w2.data_ptr(), b2.data_ptr() if b2 is not None else None,
-                                    group_offsets.data_ptr(), G, n_local, max_rows, M, I,
-                                    h.data_ptr(), y.data_ptr(), _stream_ptr(a))
-    _lib.check(rc, "moe_expert_ffn_fwd")
+        if timer is None:
+            rc = lib.moe_expert_ffn_fwd(act, a.data_ptr(), a.stride(0), gp, gather_shift, w1.data_ptr(), b1p,
+                                        w2.data_ptr(), b2p, group_offsets.data_ptr(), G, n_local, max_rows, M, I,
+                                        h.data_ptr(), y.data_ptr(), _stream_ptr(a))
+            _lib.check(rc, "moe_expert_ffn_fwd")
+        else:
+            # same two launches through the single-GEMM primitive, with events between them
+            epi = EPI_SWIGLU if act == ACT_SWIGLU else EPI_GELU_NEW
+            timer.mark("fc1_begin")
+            rc = lib.moe_grouped_gemm_fwd(epi, a.data_ptr(), a.stride(0), gp, gather_shift, w1.data_ptr(), b1p,
+                                          group_offsets.data_ptr(), G, n_local, max_rows, M, I, h.data_ptr(), I,
+                                          _stream_ptr(a))
+            _lib.check(rc, "moe_grouped_gemm_fwd(fc1)")
+            timer.mark("fc1_end")
+            rc = lib.moe_grouped_gemm_fwd(EPI_PLAIN, h.data_ptr(), I, None, 0, w2.data_ptr(), b2p,
+                                          group_offsets.data_ptr(), G, n_local, max_rows, I, M, y.data_ptr(), M,
+                                          _stream_ptr(a))
+            _lib.check(rc, "moe_grouped_gemm_fwd(fc2)")
+            timer.mark("fc2_end")
     return y
 
 

@@ -107,6 +107,8 @@ class MOELayer(nn.Module):
         self.l_aux: Optional[Tensor] = None
         self.exp_counts: Optional[Tensor] = None
         self.last_routing: Optional[ops.Routing] = None
+        #: set to an ops.PhaseTimer to record HIP events around gate / fc1 / fc2 / combine (wall_clock_breakdown)
+        self.timer: Optional[ops.PhaseTimer] = None
         self._warned_grad = False
 
     def _set_ep_group(self, ep_group):
@@ -129,14 +131,21 @@ class MOELayer(nn.Module):
         if not x.is_contiguous():
             x = x.contiguous()
         S = x.shape[0]
+        t = self.timer
+        if t is not None:
+            t.mark("gate_begin")
         r = self.gate(x, used_token)
+        if t is not None:
+            t.mark("gate_end")
         self.l_aux, self.exp_counts, self.last_routing = r.l_aux, r.exp_counts, r
         act, w1, b1, w2, b2 = self.experts.packed(x.device)
         if self.ep_size == 1:
-            y = ops.expert_ffn(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows)
+            y = ops.expert_ffn(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows, timer=t)
         else:
             y = self._expert_parallel(x, r, act, w1, b1, w2, b2)
         out = ops.combine(y, r, S, M)
+        if t is not None:
+            t.mark("combine_end")
         return out.reshape(x_in.shape)
 
     # ------------------------------------------------------------------------------------------
@@ -169,7 +178,7 @@ class MOELayer(nn.Module):
         offs_h = torch.zeros(ep * El + 1, dtype=torch.int32)
         offs_h[1:] = torch.cumsum(recv_mat.reshape(-1), 0).to(torch.int32)
         offs = offs_h.to(x.device, non_blocking=True)
-        y_recv = ops.expert_ffn(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv)
+        y_recv = ops.expert_ffn(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv, timer=self.timer)
         y = torch.empty((max(n_send, r.max_rows, 1), M), dtype=torch.bfloat16, device=x.device)
         dist.all_to_all_single(y[:n_send], y_recv[:n_recv], send_splits, recv_splits, group=self.ep_group)
         return y
