@@ -90,6 +90,40 @@ class TopKGate(nn.Module):
         return ops.routing_top2(lg, cap, noise, self.drop_tokens)
 
 
+def _group_is_gloo(group) -> bool:
+    import torch.distributed as dist
+    try:
+        return dist.get_backend(group) == "gloo"
+    except Exception:
+        return False
+
+
+def _all_to_all_rows(out: Tensor, inp: Tensor, out_splits, in_splits, group) -> None:
+    """Variable-split all_to_all_single on dim 0.  RCCL (backend "nccl") moves device buffers directly over
+    xGMI.  A gloo group (CPU rehearsals, or several ranks sharing one GPU in the tests) cannot take device
+    tensors, so for gloo only the payload is staged through host memory; the compute never is."""
+    import torch.distributed as dist
+    if inp.is_cuda and _group_is_gloo(group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+        return
+    dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+
+
+def _all_gather_counts(local: Tensor, ep: int, group) -> Tensor:
+    """[ep, E] int32 matrix of every EP rank's kept counts, on the host."""
+    import torch.distributed as dist
+    if local.is_cuda and _group_is_gloo(group):
+        loc = local.cpu()
+        allk = torch.empty((ep * loc.numel(),), dtype=loc.dtype)
+        dist.all_gather_into_tensor(allk, loc, group=group)
+        return allk.reshape(ep, -1)
+    allk = torch.empty((ep * local.numel(),), dtype=local.dtype, device=local.device)   # flat: gloo wants 1-D
+    dist.all_gather_into_tensor(allk, local, group=group)
+    return allk.cpu().reshape(ep, -1)
+
+
 class MOELayer(nn.Module):
     """gate -> dispatch -> (all-to-all) -> experts -> (all-to-all) -> combine."""
 
@@ -163,22 +197,20 @@ class MOELayer(nn.Module):
         me = dist.get_rank(self.ep_group)
         E = ep * El
         M = x.shape[1]
-        # every rank learns every rank's kept counts: [ep(src), E]
-        all_kept = torch.empty((ep, E), dtype=torch.int32, device=x.device)
-        dist.all_gather_into_tensor(all_kept, r.kept_counts, group=self.ep_group)
-        kept_h = all_kept.cpu().to(torch.int64)                      # the one host sync
+        # every rank learns every rank's kept counts: [ep(src), E]; the one host sync of the call
+        kept_h = _all_gather_counts(r.kept_counts, ep, self.ep_group).to(torch.int64)
         send_splits = kept_h[me].reshape(ep, El).sum(1).tolist()     # rows I send to each rank
         recv_mat = kept_h[:, me * El:(me + 1) * El]                  # [src, le] rows I receive
         recv_splits = recv_mat.sum(1).tolist()
         n_send, n_recv = int(sum(send_splits)), int(sum(recv_splits))
         send = ops.gather_rows(x, r.perm, 1, r.expert_offsets[E:E + 1], n_send)
         recv = torch.empty((max(n_recv, 1), M), dtype=torch.bfloat16, device=x.device)
-        dist.all_to_all_single(recv[:n_recv], send[:n_send], recv_splits, send_splits, group=self.ep_group)
+        _all_to_all_rows(recv[:n_recv], send[:n_send], recv_splits, send_splits, self.ep_group)
         # received rows are ordered (src, local expert): ep*El groups, group g uses expert g % El
         offs_h = torch.zeros(ep * El + 1, dtype=torch.int32)
         offs_h[1:] = torch.cumsum(recv_mat.reshape(-1), 0).to(torch.int32)
         offs = offs_h.to(x.device, non_blocking=True)
         y_recv = ops.expert_ffn(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv, timer=self.timer)
         y = torch.empty((max(n_send, r.max_rows, 1), M), dtype=torch.bfloat16, device=x.device)
-        dist.all_to_all_single(y[:n_send], y_recv[:n_recv], send_splits, recv_splits, group=self.ep_group)
+        _all_to_all_rows(y[:n_send], y_recv[:n_recv], send_splits, recv_splits, self.ep_group)
         return y

@@ -1,0 +1,42 @@
+"""Expert-parallel path: world_size-2 gloo rehearsal on the CPU, and the real kernels with two ranks
+sharing one GPU (gloo group, payload staged through the host)."""
+import os
+import socket
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ep_worker  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(mode, kind):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(ep_worker.run, args=(2, _free_port(), mode, kind, d), nprocs=2, join=True)
+        oks = sorted(os.listdir(d))
+        assert oks == ["ok_0", "ok_1"], oks
+        return [open(os.path.join(d, f)).read() for f in oks]
+
+
+@pytest.mark.parametrize("kind", ["stablelm", "phi"])
+def test_expert_parallel_exchange_cpu_gloo(kind):
+    info = _spawn("cpu", kind)
+    assert all("dropped=" in i for i in info)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["stablelm", "phi"])
+def test_expert_parallel_two_ranks_one_gpu(kind):
+    info = _spawn("gpu", kind)
+    print(info)
