@@ -11,7 +11,8 @@ import os
 from ctypes import c_char_p, c_int, c_int64, c_size_t, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmoe_gfx950.so")
+# MOE_GFX950_LIB points the loader at another build of the same ABI (kernel A/B experiments, tools/variants)
+LIB_PATH = os.environ.get("MOE_GFX950_LIB") or os.path.join(_PKG, "libmoe_gfx950.so")
 
 ABI_VERSION = 1
 

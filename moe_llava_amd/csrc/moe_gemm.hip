@@ -25,9 +25,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int BM = 256;   // rows per tile
 constexpr int BNW = 256;  // W rows per tile (gated: 128 output columns, plain: 256)
-constexpr int BK = 64;
+#ifndef GEMM_BK
+#define GEMM_BK 64
+#endif
+constexpr int BK = GEMM_BK;  // K slice per ring slot: 64 (2 slots, one barrier per 64 of K) or 32 (4 slots)
 constexpr int NTHREADS = 512;
-constexpr int RS = 4;  // row tiles per super-row (L2 reuse of the W panel inside an XCD)
+#ifndef GEMM_RS
+#define GEMM_RS 4
+#endif
+#ifndef GEMM_AUX
+#define GEMM_AUX 0
+#endif
+constexpr int RS = GEMM_RS;  // row tiles per super-row (L2 reuse of the W panel inside an XCD)
 
 enum { EPI_PLAIN = MOE_EPI_PLAIN, EPI_SWIGLU = MOE_EPI_SWIGLU, EPI_GELU_NEW = MOE_EPI_GELU_NEW };
 
@@ -57,16 +66,16 @@ __device__ __forceinline__ void glds16(const bf16_t *gsrc, bf16_t *lds_wave_base
         reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(gsrc)),
         reinterpret_cast<__attribute__((address_space(3))) void *>(
             static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_wave_base))),
-        16, 0, 0);
+        16, 0, GEMM_AUX);
 }
 
 __device__ __forceinline__ float fast_silu(float a) {
     // a / (1 + exp(-a)); the result is rounded to bf16 right after, v_exp/v_rcp precision is ample
-    return a * __frcp_rn(1.f + __expf(-a));
+    return a * __builtin_amdgcn_rcpf(1.f + __expf(-a));
 }
 __device__ __forceinline__ float fast_tanh(float u) {
     // tanh(u) = 1 - 2 / (1 + exp(2u)); saturates correctly for |u| large
-    return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * u));
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * u));
 }
 // HF NewGELUActivation evaluated the way a bf16 tensor goes through it: every elementwise op rounds to bf16
 // (phi/modeling_phi.py:207,213 with hidden_act "gelu_new", phi/configuration_phi.py:128).
@@ -81,15 +90,36 @@ __device__ __forceinline__ float gelu_new_bf16(float x) {
     return rbf(t6 * t5);
 }
 
+// LDS: a ring of NS slots, each one K slice of BK: X tile [256][BK] bf16 + W tile [256][BK] bf16.
+// After the K loop the same memory holds the bf16 output tile [256][NC] (+16 B row pad) for full-line stores.
+#ifndef GEMM_NS
+#define GEMM_NS (GEMM_BK == 64 ? 2 : 4)
+#endif
+constexpr int NS = GEMM_NS;  // 3..5 ring slots; NS-1 K slices in flight behind the one being consumed
+constexpr int STAGE_BYTES = 2 * BM * BK * 2;                  // 64 KiB (BK 64) or 32 KiB (BK 32)
+constexpr int EPI_PAD = 16;                                   // bytes of row padding in the output image
+constexpr int LDS_BYTES = (NS * STAGE_BYTES > BM * (BNW * 2 + EPI_PAD)) ? NS * STAGE_BYTES : BM * (BNW * 2 + EPI_PAD);
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    // my own LDS-DMA pieces of the stage have landed (all but the N youngest), then everybody's have; also every
+    // wave is past its reads of the buffer that is restaged next.  Raw s_barrier: __syncthreads() would drain vmcnt.
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 template <int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][BM * BK];  // [buf][X | W][row][64], 128 KiB
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
     // ---- block -> (row tile, col tile): XCD-contiguous chunks, then super-rows of RS row tiles ----
     const int nwg = gridDim.x;
     const int bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+#ifdef GEMM_NO_XCD
+    const int swz = bid; (void)q8; (void)r8; (void)xcd;
+#else
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+#endif
     const int CT = p.col_tiles;
     const int per_sr = RS * CT;
     const int sr = swz / per_sr;
@@ -121,15 +151,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
 
-    // ---- staging sources: wave handles the 8-row groups wave*4 .. wave*4+3 of both tiles ----
-    const bf16_t *a_src[4];
-    const bf16_t *w_src[4];
+    // ---- staging sources.  One LDS-DMA piece = one wave instruction = 1 KiB = PR rows x (BK*2) bytes, lane-linear
+    //      in LDS; the wave handles NP consecutive pieces of both tiles.  LDS slot c (16 B) of a row holds source chunk
+    //      c ^ xsw(row), which makes every 16-lane ds_read_b128 group of the fragment reads hit 16 distinct 16-B bank
+    //      slots (xsw is applied on the per-lane SOURCE address and again on the read; the LDS image stays linear). ----
+    constexpr int CH = BK / 8;           // 16-byte chunks per row (4 or 8)
+    constexpr int PR = 64 / CH;          // rows per piece (16 or 8)
+    constexpr int NP = BM / PR / 8;      // pieces per wave per tile (2 or 4)
+    auto xsw = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((4 - ((row >> 2) & 3)) & 3); };
+    const bf16_t *a_src[NP];
+    const bf16_t *w_src[NP];
     {
-        const int rr = lane >> 3, c = lane & 7;
+        const int rr = lane / CH, c = lane % CH;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = (wave * 4 + j) * 8 + rr;     // 0..255
-            const int cs = c ^ ((row >> 1) & 7);         // source chunk landing in LDS slot c of this row
+        for (int j = 0; j < NP; ++j) {
+            const int row = (wave * NP + j) * PR + rr;   // 0..255
+            const int cs = c ^ xsw(row);
             int prow = row_begin + row;
             if (prow > row_end - 1) prow = row_end - 1;  // clamp: rows past the group end are never stored
             const long long srow = p.gather ? (long long)(p.gather[prow] >> p.gather_shift) : (long long)prow;
@@ -144,22 +181,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             w_src[j] = wbase + (long long)wrow * p.K + cs * 8;
         }
     }
+    bf16_t *const lds_e = reinterpret_cast<bf16_t *>(lds);
     auto stage = [&](int buf, int kt) {
+        bf16_t *xa = lds_e + buf * (STAGE_BYTES / 2) + wave * NP * 512;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(a_src[j] + kt * BK, &lds[buf][0][(wave * 4 + j) * 8 * BK]);
-            glds16(w_src[j] + kt * BK, &lds[buf][1][(wave * 4 + j) * 8 * BK]);
+        for (int j = 0; j < NP; ++j) {
+            glds16(a_src[j] + kt * BK, xa + j * 512);
+            glds16(w_src[j] + kt * BK, xa + BM * BK + j * 512);
         }
     };
 
-    // ---- fragment read offsets (elements) ----
+    // ---- fragment read offsets (elements): lane (fr, fq) reads row 16*t + fr, k chunk ks*4 + fq ----
     const int fr = lane & 15, fq = lane >> 4;
-    const int fsw = fr >> 1;  // (row >> 1) & 7 for row = 16*t + fr
-    int koff[2];
-    koff[0] = ((0 + fq) ^ fsw) * 8;
-    koff[1] = ((4 + fq) ^ fsw) * 8;
-    const int x_row0 = (wm * 128 + fr) * BK;
-    const int w_row0 = (wn * 64 + fr) * BK;
+    constexpr int KS = BK / 32;  // MFMA k-steps per slot
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = ((ks * 4 + fq) ^ xsw(fr)) * 8;
+    const int x_off = (wm * 128 + fr) * BK;
+    const int w_off = BM * BK + (wn * 64 + fr) * BK;
 
     f32x4_t acc[4][8];
 #pragma unroll
@@ -167,93 +206,134 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf) acc[nf][mf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    stage(0, 0);
+    const int nk = p.K / BK;  // >= 1 (K % 64 == 0)
+    // K loop: ring of NS slots, NS-1 K slices of LDS-DMA in flight behind the one being consumed, one counted
+    // vmcnt + raw s_barrier per slice.  At step kt the slices issued behind kt are min(NS-2, nk-1-kt), 2*NP LDS-DMA
+    // pieces per wave each.  (Measured: one barrier per 64 of K with 2 slots beats 32 of K with 4 or 5 slots.)
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s, s);
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed for every wave, and every wave has finished reading buffer (kt+1)&1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const bf16_t *lx = &lds[kt & 1][0][0];
-        const bf16_t *lw = &lds[kt & 1][1][0];
+        const int ahead = nk - 1 - kt;
+        switch (ahead < NS - 2 ? ahead : NS - 2) {
+            case 0: wait_vm_barrier<0>(); break;
+            case 1: wait_vm_barrier<2 * NP>(); break;
+            case 2: wait_vm_barrier<4 * NP>(); break;
+            default: wait_vm_barrier<6 * NP>(); break;
+        }
+#if !defined(GEMM_ABLATE_NO_LOAD) && !defined(GEMM_EXP_LATE_STAGE)
+        if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
+#endif
+#ifndef GEMM_ABLATE_NO_MFMA
+        const bf16_t *lb = lds_e + (kt % NS) * (STAGE_BYTES / 2);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8_t xf[8], wf[4];
-#pragma unroll
-            for (int mf = 0; mf < 8; ++mf)
-                xf[mf] = *reinterpret_cast<const bf16x8_t *>(lx + x_row0 + mf * 16 * BK + koff[ks]);
+#ifdef GEMM_EXP_LATE_STAGE
+            if (ks == KS - 1 && kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
+#endif
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
-                wf[nf] = *reinterpret_cast<const bf16x8_t *>(lw + w_row0 + nf * 16 * BK + koff[ks]);
+                wf[nf] = *reinterpret_cast<const bf16x8_t *>(lb + w_off + nf * 16 * BK + koff[ks]);
+#pragma unroll
+            for (int mf = 0; mf < 8; ++mf)
+                xf[mf] = *reinterpret_cast<const bf16x8_t *>(lb + x_off + mf * 16 * BK + koff[ks]);
+#ifndef GEMM_NO_SETPRIO
+            __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster together (+1..3 % measured)
+#endif
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
                 for (int mf = 0; mf < 8; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+#ifndef GEMM_NO_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
+#endif
     }
+#ifdef GEMM_ABLATE_NO_STORE
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf) asm volatile("" ::"v"(acc[nf][mf]));
+    return;
+#endif
 
-    // ---- epilogue: lane owns columns c0..c0+3 of row (mf*16 + fr) for every (nf, mf) ----
+    // ---- epilogue: activation in registers -> bf16 tile image in LDS -> 16-byte, full-line global stores ----
+    constexpr int NC = (EPI == EPI_SWIGLU) ? BNW / 2 : BNW;  // output columns per tile
+    constexpr int ROWB = NC * 2 + EPI_PAD;                   // bytes per image row
     const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
+    __syncthreads();  // every wave is done reading the ring
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
-            const int c0 = ct * (BNW / 2) + wn * 32 + nf * 16 + fq * 4;
-            if (c0 < p.N_out) {
-                float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
-                if (bias) {
+            const int cl = wn * 32 + nf * 16 + fq * 4;  // column inside the tile
+            const int c0 = ct * NC + cl;
+            float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias && c0 < p.N_out) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ba[j] = bf2f(bias[c0 + j]);
-                        bb[j] = bf2f(bias[p.b_row_offset + c0 + j]);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    ba[j] = bf2f(bias[c0 + j]);
+                    bb[j] = bf2f(bias[p.b_row_offset + c0 + j]);
                 }
+            }
 #pragma unroll
-                for (int mf = 0; mf < 8; ++mf) {
-                    const int prow = row_begin + wm * 128 + mf * 16 + fr;
-                    if (prow < row_end) {
-                        unsigned short h[4];
+            for (int mf = 0; mf < 8; ++mf) {
+                unsigned short h[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float a = rbf(acc[nf][mf][j] + ba[j]);       // bf16 output of the 'a' Linear
-                            const float b = rbf(acc[nf + 2][mf][j] + bb[j]);   // bf16 output of the 'b' Linear
-                            const float s = rbf(fast_silu(a));                 // F.silu on a bf16 tensor
-                            h[j] = f2bf(s * b);
-                        }
-                        uint2 o;
-                        o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-                        o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-                        *reinterpret_cast<uint2 *>(p.out + (long long)prow * p.ldo + c0) = o;
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const float a = rbf(acc[nf][mf][j] + ba[j]);      // bf16 output of the 'a' Linear
+                    const float b = rbf(acc[nf + 2][mf][j] + bb[j]);  // bf16 output of the 'b' Linear
+                    const float sg = rbf(fast_silu(a));               // F.silu on a bf16 tensor
+                    h[j] = f2bf(sg * b);
                 }
+                uint2 o;
+                o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+                o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+                *reinterpret_cast<uint2 *>(lds + (wm * 128 + mf * 16 + fr) * ROWB + cl * 2) = o;
             }
         }
     } else {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-            const int c0 = ct * BNW + wn * 64 + nf * 16 + fq * 4;
-            if (c0 < p.N_out) {
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (bias) {
+            const int cl = wn * 64 + nf * 16 + fq * 4;
+            const int c0 = ct * NC + cl;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias && c0 < p.N_out) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[j] = bf2f(bias[c0 + j]);
+                for (int j = 0; j < 4; ++j) bv[j] = bf2f(bias[c0 + j]);
+            }
+#pragma unroll
+            for (int mf = 0; mf < 8; ++mf) {
+                unsigned short h[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = rbf(acc[nf][mf][j] + bv[j]);  // bf16 output of the Linear
+                    h[j] = (EPI == EPI_GELU_NEW) ? f2bf(gelu_new_bf16(v)) : f2bf(v);
                 }
-#pragma unroll
-                for (int mf = 0; mf < 8; ++mf) {
-                    const int prow = row_begin + wm * 128 + mf * 16 + fr;
-                    if (prow < row_end) {
-                        unsigned short h[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v = rbf(acc[nf][mf][j] + bv[j]);  // bf16 output of the Linear
-                            h[j] = (EPI == EPI_GELU_NEW) ? f2bf(gelu_new_bf16(v)) : f2bf(v);
-                        }
-                        uint2 o;
-                        o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-                        o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-                        *reinterpret_cast<uint2 *>(p.out + (long long)prow * p.ldo + c0) = o;
-                    }
-                }
+                uint2 o;
+                o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+                o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+                *reinterpret_cast<uint2 *>(lds + (wm * 128 + mf * 16 + fr) * ROWB + cl * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPR = NC / 8;                    // 16-byte chunks per row
+        constexpr int ROWS_PER_IT = NTHREADS / CPR;    // rows covered by one pass of the block
+        const int cc = tid % CPR, r0 = tid / CPR;
+        const int col = ct * NC + cc * 8;
+        const int ncols_ok = p.N_out - col;            // > 0 columns valid from here (N_out % 4 == 0)
+#pragma unroll 4
+        for (int r = r0; r < BM; r += ROWS_PER_IT) {
+            const int prow = row_begin + r;
+            if (prow < row_end && ncols_ok > 0) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(lds + r * ROWB + cc * 16);
+                bf16_t *dst = p.out + (long long)prow * p.ldo + col;
+                if (ncols_ok >= 8) *reinterpret_cast<uint4 *>(dst) = v;
+                else *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
             }
         }
     }
@@ -274,7 +354,7 @@ using namespace moe;
 static int gemm_args_ok(const char *fn, const void *a, int64_t lda, int gather_shift, const void *w, const int32_t *group_offsets,
                         int G, int n_experts_local, int max_rows, int K, int N, const void *out, int64_t ldo) {
     if (!a || !w || !group_offsets || !out) return fail(MOE_ERR_ARG, "%s: null pointer", fn);
-    if (K <= 0 || N <= 0 || (K % BK) || (N & 3) || G < 1 || G > 4096 || n_experts_local < 1 || max_rows < 0 ||
+    if (K <= 0 || N <= 0 || (K % 64) || (N & 3) || G < 1 || G > 4096 || n_experts_local < 1 || max_rows < 0 ||
         gather_shift < 0 || gather_shift > 1 || lda < K || (lda & 7) || ldo < N || (ldo & 3))
         return fail(MOE_ERR_SHAPE,
                     "%s: need K%%64==0, N%%4==0, 1<=G<=4096, lda>=K, lda%%8==0, ldo>=N, ldo%%4==0 (K=%d N=%d G=%d lda=%lld ldo=%lld)",
@@ -329,7 +409,7 @@ extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int
                                   void *h_ws, void *y, void *stream) {
     if (!h_ws || !y || !w2) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: null pointer");
     if (act != MOE_ACT_SWIGLU && act != MOE_ACT_GELU_NEW) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: unknown act %d", act);
-    if (M <= 0 || I <= 0 || (M % BK) || (I % BK))
+    if (M <= 0 || I <= 0 || (M % 64) || (I % 64))
         return fail(MOE_ERR_SHAPE, "moe_expert_ffn_fwd: need M%%64==0 and I%%64==0 (M=%d I=%d)", M, I);
     // validate the second GEMM before launching the first, so a bad call launches nothing
     int rc = gemm_args_ok("moe_expert_ffn_fwd", h_ws, I, 0, w2, group_offsets, G, n_experts_local, max_rows, I, M, y, M);
