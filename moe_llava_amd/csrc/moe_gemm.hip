@@ -100,6 +100,19 @@ constexpr int STAGE_BYTES = 2 * BM * BK * 2;                  // 64 KiB (BK 64) 
 constexpr int EPI_PAD = 16;                                   // bytes of row padding in the output image
 constexpr int LDS_BYTES = (NS * STAGE_BYTES > BM * (BNW * 2 + EPI_PAD)) ? NS * STAGE_BYTES : BM * (BNW * 2 + EPI_PAD);
 
+#ifdef GEMM_STAMPS
+// Diagnostic build only (cdna guide section 7, in-kernel stamps): per-wave cycle sums of the K-loop segments go to a
+// buffer of their own, never to an output.
+__device__ unsigned long long g_stamps[8 * 8 * 8];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
     // my own LDS-DMA pieces of the stage have landed (all but the N youngest), then everybody's have; also every
@@ -157,7 +170,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     //      slots (xsw is applied on the per-lane SOURCE address and again on the read; the LDS image stays linear). ----
     constexpr int CH = BK / 8;           // 16-byte chunks per row (4 or 8)
     constexpr int PR = 64 / CH;          // rows per piece (16 or 8)
-    constexpr int NP = BM / PR / 8;      // pieces per wave per tile (2 or 4)
+#ifndef GEMM_LOADER_WAVES
+#define GEMM_LOADER_WAVES 4
+#endif
+    // Waves 0..LW-1 issue the LDS-DMA.  In-kernel stamps: a 1-KiB piece is accepted every ~80 cycles, so issuing a
+    // slice's 64 pieces from all 8 waves cost each wave 640-1500 cycles at the head of every step with its SIMD's
+    // matrix pipe idle.  With LW = 4 (one loader per SIMD) the partner wave starts its MFMAs at once: +2..4 %.
+    constexpr int LW = GEMM_LOADER_WAVES;
+    constexpr int NP = BM / PR / LW;        // pieces per loader wave per tile
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) < LW;
+    const int lwave = wave % LW;
     auto xsw = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((4 - ((row >> 2) & 3)) & 3); };
     const bf16_t *a_src[NP];
     const bf16_t *w_src[NP];
@@ -165,7 +187,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         const int rr = lane / CH, c = lane % CH;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int row = (wave * NP + j) * PR + rr;   // 0..255
+            const int row = (lwave * NP + j) * PR + rr;  // 0..255
             const int cs = c ^ xsw(row);
             int prow = row_begin + row;
             if (prow > row_end - 1) prow = row_end - 1;  // clamp: rows past the group end are never stored
@@ -183,7 +205,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     }
     bf16_t *const lds_e = reinterpret_cast<bf16_t *>(lds);
     auto stage = [&](int buf, int kt) {
-        bf16_t *xa = lds_e + buf * (STAGE_BYTES / 2) + wave * NP * 512;
+        if (!loader) return;
+        bf16_t *xa = lds_e + buf * (STAGE_BYTES / 2) + lwave * NP * 512;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             glds16(a_src[j] + kt * BK, xa + j * 512);
@@ -213,6 +236,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) stage(s, s);
+#ifdef GEMM_STAMPS
+    unsigned long long st_wait = 0, st_issue = 0, st_comp = 0, st_t0 = stamp(), st_begin = st_t0;
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         const int ahead = nk - 1 - kt;
         switch (ahead < NS - 2 ? ahead : NS - 2) {
@@ -221,17 +247,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             case 2: wait_vm_barrier<4 * NP>(); break;
             default: wait_vm_barrier<6 * NP>(); break;
         }
-#if !defined(GEMM_ABLATE_NO_LOAD) && !defined(GEMM_EXP_LATE_STAGE)
+#ifdef GEMM_STAMPS
+        const unsigned long long st_t1 = stamp();
+#endif
+#ifndef GEMM_ABLATE_NO_LOAD
         if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
+#endif
+#ifdef GEMM_STAMPS
+        const unsigned long long st_t2 = stamp();
 #endif
 #ifndef GEMM_ABLATE_NO_MFMA
         const bf16_t *lb = lds_e + (kt % NS) * (STAGE_BYTES / 2);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             bf16x8_t xf[8], wf[4];
-#ifdef GEMM_EXP_LATE_STAGE
-            if (ks == KS - 1 && kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
-#endif
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
                 wf[nf] = *reinterpret_cast<const bf16x8_t *>(lb + w_off + nf * 16 * BK + koff[ks]);
@@ -242,16 +271,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster together (+1..3 % measured)
 #endif
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < 4; ++nf) {
 #pragma unroll
                 for (int mf = 0; mf < 8; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+            }
 #ifndef GEMM_NO_SETPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
         }
 #endif
+#ifdef GEMM_STAMPS
+        const unsigned long long st_t3 = stamp();
+        st_wait += st_t1 - st_t0; st_issue += st_t2 - st_t1; st_comp += st_t3 - st_t2; st_t0 = st_t3;
+#endif
     }
+#ifdef GEMM_STAMPS
+    const unsigned long long st_loop_end = stamp();
+#endif
 #ifdef GEMM_ABLATE_NO_STORE
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf)
@@ -337,6 +374,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             }
         }
     }
+#ifdef GEMM_STAMPS
+    {
+        const unsigned long long st_end = stamp();
+        if (lane == 0 && blockIdx.x >= 1024 && blockIdx.x < 1032) {
+            unsigned long long *o = g_stamps + ((blockIdx.x - 1024) * 8 + wave) * 8;
+            o[0] = st_wait; o[1] = st_issue; o[2] = st_comp; o[3] = st_loop_end - st_begin; o[4] = st_end - st_loop_end;
+            o[5] = nk; o[6] = st_begin; o[7] = st_end;
+        }
+    }
+#endif
 }
 
 template <int EPI>
@@ -362,6 +409,12 @@ static int gemm_args_ok(const char *fn, const void *a, int64_t lda, int gather_s
     if (!aligned16(a) || !aligned16(w) || !aligned16(out)) return fail(MOE_ERR_ALIGN, "%s: pointers must be 16-byte aligned", fn);
     return 0;
 }
+
+#ifdef GEMM_STAMPS
+extern "C" int moe_debug_read_stamps(unsigned long long *host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(moe::g_stamps), sizeof(unsigned long long) * 512);
+}
+#endif
 
 extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                     const void *w, const void *bias, const int32_t *group_offsets, int G,

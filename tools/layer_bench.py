@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Per-phase timing of the MoE block at the BASELINE.json configs that fit one GPU (single-GPU shapes).
+Not the contract bench (that is bench.py); this is the tuning aid: HIP-event phase breakdown per config."""
+import argparse
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import moe_llava_amd  # noqa: E402
+from moe_llava_amd import ops  # noqa: E402
+from moe_llava_amd.expert_mlps import PhiMLP, QWenMLP, StableLMMLP  # noqa: E402
+
+CONFIGS = {
+    # name: (expert ctor, M, I, E, cf, S, training)
+    "cfg1_stablelm_S704": (StableLMMLP, 2048, 5632, 4, 1.5, 704, True),
+    "cfg2_stablelm_S22528": (StableLMMLP, 2048, 5632, 4, 1.5, 22528, True),
+    "cfg3_phi_S13712": (PhiMLP, 2560, 10240, 4, 1.5, 13712, True),
+    "cfg4_qwen_S2432": (QWenMLP, 2048, 5504, 4, 1.5, 2432, True),
+    "cfg5_phi8e_S16384": (PhiMLP, 2560, 10240, 8, 1.25, 16384, True),
+    "decode_stablelm_S32": (StableLMMLP, 2048, 5632, 4, 2.0, 32, False),
+    "decode_stablelm_S1": (StableLMMLP, 2048, 5632, 4, 2.0, 1, False),
+}
+
+
+def run(name, iters, warmup):
+    ctor, M, I, E, cf, S, training = CONFIGS[name]
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    moe = moe_llava_amd.MoE(M, ctor(M, I).to(torch.bfloat16), num_experts=E, k=2, capacity_factor=cf,
+                            eval_capacity_factor=2.0, min_capacity=0)
+    for p in moe.deepspeed_moe.experts.parameters():
+        p.data.normal_(0, 0.02)
+    moe.deepspeed_moe.gate.wg.weight.data.normal_(0, 0.02)
+    moe = moe.to(dev).train(training)
+    x = torch.randn(1, S, M, device=dev).to(torch.bfloat16)
+    with torch.no_grad():
+        for _ in range(warmup):
+            moe(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            moe(x)
+        e1.record()
+        torch.cuda.synchronize()
+        total = e0.elapsed_time(e1) / iters
+        t = ops.PhaseTimer()
+        moe.deepspeed_moe.timer = t
+        for _ in range(iters):
+            moe(x)
+        moe.deepspeed_moe.timer = None
+        ph = {k: statistics.mean(t.durations(a, b)) for k, (a, b) in
+              {"gate+route": ("gate_begin", "gate_end"), "fc1": ("fc1_begin", "fc1_end"),
+               "fc2": ("fc1_end", "fc2_end"), "combine": ("fc2_end", "combine_end")}.items()}
+    rows = int(moe.deepspeed_moe.last_routing.expert_offsets[-1])
+    nmat = 3 if ctor is not PhiMLP else 2
+    flops = 2.0 * rows * nmat * M * I
+    wbytes = E * nmat * M * I * 2
+    print(f"{name:24s} {total*1e3:9.1f} us/step  {S/total/1e3:9.2f} Mtok/s  {flops/total/1e9:7.1f} TF  "
+          f"weights {wbytes/total/1e6:7.0f} GB/s | " + "  ".join(f"{k} {v*1e3:.1f}us" for k, v in ph.items()), flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("configs", nargs="*", default=list(CONFIGS))
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    a = ap.parse_args()
+    for c in a.configs:
+        run(c, a.iters, a.warmup)
