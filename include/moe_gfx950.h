@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 1
+#define MOE_ABI_VERSION 2
 
 /* activation / expert-MLP form of moe_expert_ffn_fwd */
 #define MOE_ACT_SWIGLU   0 /* h = silu(Wa x) * (Wb x); W1 = [Wa ; Wb] ([2I, M]).  StableLM: Wa=gate_proj, Wb=up_proj
@@ -64,7 +64,10 @@ size_t moe_routing_workspace_bytes(int S, int E);
  * l_aux / exp_counts -> dispatch index, from fp32 logits.  Index form of SURVEY 8(a').
  *   logits      [S,E] fp32 (read only)
  *   noise       [S,E] fp32 or NULL: added to the logits for the SECOND choice only
- *               (top2_2nd_expert_sampling; NULL = deterministic branch)
+ *               (top2_2nd_expert_sampling).  NULL and noise_seed == 0 = deterministic branch.
+ *   noise_seed  non-zero (with noise == NULL): Gumbel(0,1) noise is generated in the kernel, Philox4x32-10
+ *               keyed by the seed with counter (token, expert/4) -- what upstream's gumbel_rsample does, without
+ *               the extra elementwise launches
  *   capacity    C, computed on the host exactly as upstream _capacity (ignored when drop_tokens = 0,
  *               then capacity = max_e exp_counts[e] and nothing is dropped)
  *   expert_idx  [S,2] int32   chosen experts (first, second)
@@ -75,9 +78,9 @@ size_t moe_routing_workspace_bytes(int S, int E);
  *   expert_offsets [E+1] int32 exclusive prefix of kept_counts
  *   perm        [min(2S, E*C)] int32  perm[expert_offsets[e] + slot] = token*2 + choice
  *   l_aux       [1]   fp32
- * 2 <= E <= 64.  Three launches.
+ * 2 <= E <= 64.  One launch when S <= 4096 and E <= 16 (single-block kernel), three otherwise.
  */
-int moe_routing_top2_fwd(const float *logits, const float *noise, int S, int E, int capacity,
+int moe_routing_top2_fwd(const float *logits, const float *noise, uint64_t noise_seed, int S, int E, int capacity,
                          int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
                          int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets,
                          int32_t *perm, float *l_aux, void *workspace, size_t ws_bytes, void *stream);

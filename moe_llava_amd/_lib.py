@@ -8,13 +8,13 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # MOE_GFX950_LIB points the loader at another build of the same ABI (kernel A/B experiments, tools/variants)
 LIB_PATH = os.environ.get("MOE_GFX950_LIB") or os.path.join(_PKG, "libmoe_gfx950.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # (name, restype, argtypes) -- must mirror include/moe_gfx950.h exactly
 _SIGNATURES = [
@@ -23,7 +23,7 @@ _SIGNATURES = [
     ("moe_gate_logits_fwd", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     ("moe_routing_workspace_bytes", c_size_t, [c_int, c_int]),
     ("moe_routing_top2_fwd", c_int,
-     [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+     [c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("moe_expert_ffn_fwd", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

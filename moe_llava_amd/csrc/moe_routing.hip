@@ -100,21 +100,33 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16_t *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// routing pass 1: per token softmax + top-2; per block (256 tokens) ranks, histograms, gate sums.
-// Temporaries are parked in the output arrays: slot <- rank inside the block, weight <- raw gates.
+// Gumbel(0,1) noise for the second choice (top2_2nd_expert_sampling): counter-based Philox4x32-10 keyed by
+// the caller's seed, counter = (token, expert / 4), so the sample of (token, expert) does not depend on the
+// launch geometry.  Upstream draws Gumbel(0,1).rsample() per (token, expert); only the distribution matters.
 // ------------------------------------------------------------------------------------------------
-template <int EMAX>
-__global__ __launch_bounds__(RB) void route_local_kernel(const float *__restrict__ logits, const float *__restrict__ noise,
-                                                         int S, int E, int nb, int *__restrict__ expert_idx,
-                                                         int *__restrict__ slot, float *__restrict__ weight,
-                                                         int *__restrict__ hist, float *__restrict__ gsum) {
-    __shared__ int wcnt[2][RB / 64][EMAX];
-    __shared__ float wsum[RB / 64][EMAX];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = blockIdx.x * RB + tid;
-    const bool valid = s < S;
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ float gumbel_from_bits(unsigned x) {
+    const float u = ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f;  // (0,1), 23 random bits, never 0 or 1
+    return -logf(-logf(u));
+}
 
-    float l[EMAX], g[EMAX];
+// softmax + top-2 of one token (SURVEY 8a' lines 1-5).  g[] returns the gates; i1 by argmax over the GATES,
+// i2 by argmax over logits (+ noise) with i1 masked; strict > everywhere keeps the lowest index on ties.
+template <int EMAX>
+__device__ __forceinline__ void select_top2(const float *__restrict__ logits, const float *__restrict__ noise,
+                                            unsigned long long seed, int s, int E, bool valid, float (&g)[EMAX], int &i1,
+                                            int &i2, float &g1, float &g2) {
+    float l[EMAX];
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) l[e] = (valid && e < E) ? logits[(size_t)s * E + e] : -INFINITY;
     float mx = l[0];
@@ -126,25 +138,56 @@ __global__ __launch_bounds__(RB) void route_local_kernel(const float *__restrict
         g[e] = (e < E) ? expf(l[e] - mx) : 0.f;
         sum += g[e];  // index order
     }
-    int i1 = 0;
-    float g1 = -1.f;
+    i1 = 0;
+    g1 = -1.f;
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
         g[e] = g[e] / sum;  // IEEE division (hipcc default: correctly rounded)
-        if (e < E && g[e] > g1) { g1 = g[e]; i1 = e; }  // strict > : lowest index wins ties
+        if (e < E && g[e] > g1) { g1 = g[e]; i1 = e; }
     }
-    int i2 = 0;
-    float best = -INFINITY, g2 = 0.f;
+    i2 = 0;
+    g2 = 0.f;
+    float best = -INFINITY;
     bool have2 = false;
+    uint4 rnd = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
+        if (seed != 0ull && (e & 3) == 0 && e < E)
+            rnd = philox4x32_10(make_uint4((unsigned)s, (unsigned)(e >> 2), 0u, 0u),
+                                make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
         if (e < E && e != i1) {
             float v = l[e];
             if (noise != nullptr && valid) v += noise[(size_t)s * E + e];
+            else if (seed != 0ull) {
+                const unsigned bits = (e & 3) == 0 ? rnd.x : (e & 3) == 1 ? rnd.y : (e & 3) == 2 ? rnd.z : rnd.w;
+                v += gumbel_from_bits(bits);
+            }
             // the first candidate is always taken; after that strict > keeps the lowest index on ties
             if (!have2 || v > best) { best = v; i2 = e; g2 = g[e]; have2 = true; }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// routing pass 1: per token softmax + top-2; per block (256 tokens) ranks, histograms, gate sums.
+// Temporaries are parked in the output arrays: slot <- rank inside the block, weight <- raw gates.
+// ------------------------------------------------------------------------------------------------
+template <int EMAX>
+__global__ __launch_bounds__(RB) void route_local_kernel(const float *__restrict__ logits, const float *__restrict__ noise,
+                                                         unsigned long long seed, int S, int E, int nb,
+                                                         int *__restrict__ expert_idx, int *__restrict__ slot,
+                                                         float *__restrict__ weight, int *__restrict__ hist,
+                                                         float *__restrict__ gsum) {
+    __shared__ int wcnt[2][RB / 64][EMAX];
+    __shared__ float wsum[RB / 64][EMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x * RB + tid;
+    const bool valid = s < S;
+
+    float g[EMAX];
+    int i1, i2;
+    float g1, g2;
+    select_top2<EMAX>(logits, noise, seed, s, E, valid, g, i1, i2, g1, g2);
     if (!valid) { i1 = -1; i2 = -1; }
 
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -283,6 +326,123 @@ __global__ __launch_bounds__(RB) void route_finalize_kernel(int S, int E, int nb
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small-S routing in ONE launch (S <= 4096, E <= 16): a single 1024-thread block keeps up to 4 tokens per thread
+// in registers (token = chunk*1024 + tid, so chunk order is token order), per-(chunk, wave) histograms in LDS,
+// scans them, and finalises.  Same arithmetic as the three-kernel path; prefill of a few samples and decode
+// steps are launch-latency bound, so the launch count is what matters there.
+// ------------------------------------------------------------------------------------------------
+constexpr int FUSED_T = 4, FUSED_THREADS = 1024, FUSED_EMAX = 16;
+template <int EMAX>
+__global__ __launch_bounds__(FUSED_THREADS) void route_fused_kernel(
+    const float *__restrict__ logits, const float *__restrict__ noise, unsigned long long seed, int S, int E, int capacity,
+    int drop_tokens, int *__restrict__ expert_idx, int *__restrict__ slot, float *__restrict__ weight,
+    long long *__restrict__ exp_counts, int *__restrict__ kept_counts, int *__restrict__ expert_offsets,
+    int *__restrict__ perm, float *__restrict__ l_aux) {
+    constexpr int NW = FUSED_THREADS / 64;
+    __shared__ int wcnt[FUSED_T][2][NW][EMAX];   // counts, then exclusive bases (token order = chunk, wave)
+    __shared__ float wsum[FUSED_T][NW][EMAX];
+    __shared__ int s_n1[EMAX], s_off[EMAX + 1], s_cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int nchunk = (S + FUSED_THREADS - 1) / FUSED_THREADS;
+    int i1[FUSED_T], i2[FUSED_T], r1[FUSED_T], r2[FUSED_T];
+    float g1[FUSED_T], g2[FUSED_T];
+#pragma unroll
+    for (int c = 0; c < FUSED_T; ++c) {
+        if (c < nchunk) {
+            const int s = c * FUSED_THREADS + tid;
+            const bool valid = s < S;
+            float g[EMAX];
+            select_top2<EMAX>(logits, noise, seed, s, E, valid, g, i1[c], i2[c], g1[c], g2[c]);
+            if (!valid) { i1[c] = -1; i2[c] = -1; }
+            r1[c] = 0;
+            r2[c] = 0;
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                if (e < E) {
+                    const unsigned long long b1 = __ballot(i1[c] == e);
+                    const unsigned long long b2 = __ballot(i2[c] == e);
+                    if (i1[c] == e) r1[c] = __popcll(b1 & lt);
+                    if (i2[c] == e) r2[c] = __popcll(b2 & lt);
+                    const float gs = wave_sum(valid ? g[e] : 0.f);
+                    if (lane == 0) {
+                        wcnt[c][0][wave][e] = __popcll(b1);
+                        wcnt[c][1][wave][e] = __popcll(b2);
+                        wsum[c][wave][e] = gs;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan over (chunk, wave) per (choice, expert); thread q = choice*E + e
+    if (tid < 2 * E) {
+        const int ch = tid / E, e = tid % E;
+        int run = 0;
+        for (int c = 0; c < nchunk; ++c)
+            for (int w = 0; w < NW; ++w) {
+                const int v = wcnt[c][ch][w][e];
+                wcnt[c][ch][w][e] = run;
+                run += v;
+            }
+        if (ch == 0) s_n1[e] = run;
+        else s_off[e] = run;  // n2, parked until thread 0 turns it into offsets
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int cap = capacity;
+        if (!drop_tokens) {
+            cap = 0;
+            for (int e = 0; e < E; ++e) cap = max(cap, s_n1[e] + s_off[e]);
+        }
+        s_cap = cap;
+        int off = 0;
+        float lsum = 0.f;
+        const float fS = (float)S;
+        for (int e = 0; e < E; ++e) {
+            const int n1 = s_n1[e], n2 = s_off[e];
+            exp_counts[e] = (long long)n1 + (long long)n2;
+            const int k1 = min(n1, cap);
+            const int k2 = max(0, min(n2, cap - n1));
+            kept_counts[e] = k1 + k2;
+            expert_offsets[e] = off;
+            s_off[e] = off;
+            off += k1 + k2;
+            double gs = 0.0;
+            for (int c = 0; c < nchunk; ++c)
+                for (int w = 0; w < NW; ++w) gs += (double)wsum[c][w][e];
+            const float me = (float)gs / fS;
+            const float ce = (float)n1 / fS;
+            lsum += me * ce;
+        }
+        expert_offsets[E] = off;
+        s_off[E] = off;
+        const float fE = (float)E;
+        l_aux[0] = ((lsum / fE) * fE) * fE;
+    }
+    __syncthreads();
+    const int cap = s_cap;
+#pragma unroll
+    for (int c = 0; c < FUSED_T; ++c) {
+        if (c < nchunk) {
+            const int s = c * FUSED_THREADS + tid;
+            if (s < S) {
+                const int p1 = wcnt[c][0][wave][i1[c]] + r1[c];
+                const int p2 = s_n1[i2[c]] + wcnt[c][1][wave][i2[c]] + r2[c];
+                const bool k1 = p1 < cap, k2 = p2 < cap;
+                const float a1 = k1 ? g1[c] : 0.f, a2 = k2 ? g2[c] : 0.f;
+                const float den = fmaxf(a1 + a2, 1.1920928955078125e-07f);
+                reinterpret_cast<int2 *>(expert_idx)[s] = make_int2(i1[c], i2[c]);
+                reinterpret_cast<float2 *>(weight)[s] = make_float2(a1 / den, a2 / den);
+                reinterpret_cast<int2 *>(slot)[s] = make_int2(k1 ? p1 : -1, k2 ? p2 : -1);
+                if (k1) perm[s_off[i1[c]] + p1] = 2 * s;
+                if (k2) perm[s_off[i2[c]] + p2] = 2 * s + 1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // row gather (expert-parallel send buffer) and weighted combine.  Both stream whole rows, 16 B per lane.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t *__restrict__ src, const int *__restrict__ gather,
@@ -405,26 +565,39 @@ extern "C" size_t moe_routing_workspace_bytes(int S, int E) {
     return carve(nullptr, S, E).total;
 }
 
-extern "C" int moe_routing_top2_fwd(const float *logits, const float *noise, int S, int E, int capacity, int drop_tokens,
-                                    int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
-                                    int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
-                                    void *workspace, size_t ws_bytes, void *stream) {
+extern "C" int moe_routing_top2_fwd(const float *logits, const float *noise, uint64_t noise_seed, int S, int E,
+                                    int capacity, int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
+                                    int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm,
+                                    float *l_aux, void *workspace, size_t ws_bytes, void *stream) {
     if (!logits || !expert_idx || !slot || !weight || !exp_counts || !kept_counts || !expert_offsets || !perm || !l_aux ||
         !workspace)
         return fail(MOE_ERR_ARG, "moe_routing_top2_fwd: null pointer");
     if (S < 1 || E < 2 || E > 64)
         return fail(MOE_ERR_SHAPE, "moe_routing_top2_fwd: need S>=1 and 2<=E<=64 (S=%d E=%d)", S, E);
     if (drop_tokens && capacity < 0) return fail(MOE_ERR_SHAPE, "moe_routing_top2_fwd: negative capacity");
+    if (noise && noise_seed) return fail(MOE_ERR_ARG, "moe_routing_top2_fwd: give a noise tensor or a seed, not both");
     if (!aligned16(workspace) || ((uintptr_t)expert_idx & 7) || ((uintptr_t)slot & 7) || ((uintptr_t)weight & 7))
         return fail(MOE_ERR_ALIGN, "moe_routing_top2_fwd: workspace needs 16-byte, [S,2] arrays 8-byte alignment");
     RoutingWs ws = carve(workspace, S, E);
     if (ws_bytes < ws.total)
         return fail(MOE_ERR_WORKSPACE, "moe_routing_top2_fwd: workspace %zu < %zu bytes", ws_bytes, ws.total);
     hipStream_t st = (hipStream_t)stream;
+    const unsigned long long seed = (unsigned long long)noise_seed;
+    if (S <= FUSED_T * FUSED_THREADS && E <= FUSED_EMAX) {
+#define LAUNCH_FUSED(EM)                                                                                              \
+    hipLaunchKernelGGL((route_fused_kernel<EM>), dim3(1), dim3(FUSED_THREADS), 0, st, logits, noise, seed, S, E, capacity, \
+                       drop_tokens, expert_idx, slot, weight, (long long *)exp_counts, kept_counts, expert_offsets, perm,  \
+                       l_aux)
+        if (E <= 4) LAUNCH_FUSED(4);
+        else if (E <= 8) LAUNCH_FUSED(8);
+        else LAUNCH_FUSED(16);
+#undef LAUNCH_FUSED
+        return check_launch("route_fused_kernel");
+    }
     const int nb = (S + RB - 1) / RB;
 #define LAUNCH_LOCAL(EM)                                                                                              \
-    hipLaunchKernelGGL((route_local_kernel<EM>), dim3(nb), dim3(RB), 0, st, logits, noise, S, E, nb, expert_idx, slot, \
-                       weight, ws.hist, ws.gsum)
+    hipLaunchKernelGGL((route_local_kernel<EM>), dim3(nb), dim3(RB), 0, st, logits, noise, seed, S, E, nb, expert_idx, \
+                       slot, weight, ws.hist, ws.gsum)
     if (E <= 4) LAUNCH_LOCAL(4);
     else if (E <= 8) LAUNCH_LOCAL(8);
     else if (E <= 16) LAUNCH_LOCAL(16);

@@ -101,8 +101,9 @@ def gate_logits(x: Tensor, wg_weight: Tensor) -> Tensor:
 
 
 def routing_top2(logits: Tensor, capacity: int, noise: Optional[Tensor] = None,
-                 drop_tokens: bool = True) -> Routing:
-    """top2gating in index form from fp32 logits (SURVEY 8a row a5 / 8a')."""
+                 drop_tokens: bool = True, noise_seed: int = 0) -> Routing:
+    """top2gating in index form from fp32 logits (SURVEY 8a row a5 / 8a').  Second-choice sampling noise is either
+    a given [S,E] tensor or generated in the kernel from ``noise_seed`` (non-zero)."""
     _need(logits, "logits", torch.float32, 2)
     S, E = logits.shape
     if S < 1:
@@ -127,7 +128,7 @@ def routing_top2(logits: Tensor, capacity: int, noise: Optional[Tensor] = None,
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.moe_routing_top2_fwd(logits.data_ptr(), noise.data_ptr() if noise is not None else None,
-                                      S, E, int(capacity), int(bool(drop_tokens)),
+                                      int(noise_seed) & 0xFFFFFFFFFFFFFFFF, S, E, int(capacity), int(bool(drop_tokens)),
                                       expert_idx.data_ptr(), slot.data_ptr(), weight.data_ptr(),
                                       exp_counts.data_ptr(), kept.data_ptr(), offs.data_ptr(), perm.data_ptr(),
                                       l_aux.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(logits))

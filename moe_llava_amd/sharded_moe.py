@@ -84,10 +84,15 @@ class TopKGate(nn.Module):
         S, E = lg.shape
         cf = self.capacity_factor if self.training else self.eval_capacity_factor
         cap = capacity_of(S, E, cf * 2, self.min_capacity)
-        noise = None
+        noise, seed = None, 0
         if self.top2_2nd_expert_sampling:
-            noise = self.noise_override if self.noise_override is not None else gumbel_rsample(lg.shape, lg.device)
-        return ops.routing_top2(lg, cap, noise, self.drop_tokens)
+            if self.noise_override is not None:
+                noise = self.noise_override
+            else:
+                # Gumbel noise is generated inside the routing kernel (Philox keyed by this seed); the seed comes
+                # from torch's CPU generator, so torch.manual_seed() makes runs reproducible and no launch is spent
+                seed = int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())
+        return ops.routing_top2(lg, cap, noise, self.drop_tokens, noise_seed=seed)
 
 
 def _group_is_gloo(group) -> bool:

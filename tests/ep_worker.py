@@ -26,7 +26,7 @@ def _install_cpu_stand_ins():
     def gate_logits(x, wg):
         return F.linear(x.float(), wg.float())
 
-    def routing_top2(logits, capacity, noise=None, drop_tokens=True):
+    def routing_top2(logits, capacity, noise=None, drop_tokens=True, noise_seed=0):
         S, E = logits.shape
         r = ix.route_top2(logits, capacity, noise, drop_tokens)
         offs, perm = ix.dispatch_order(r, E)
