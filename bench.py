@@ -125,11 +125,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
     import torch.distributed as dist
-    device = torch.device("cuda", local_rank)
+    # BENCH_REHEARSAL=1: several ranks share cuda:0 over a gloo group (the all-to-all payload is staged through the
+    # host) -- only to rehearse the N > 1 code path on a one-GPU box; the numbers it prints are meaningless.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    device = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     ep = min(world, E)
     while E % ep or world % ep:
@@ -166,7 +172,7 @@ def main():
     elapsed = time.perf_counter() - t0
     moe.deepspeed_moe.timer = None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
 
@@ -175,13 +181,14 @@ def main():
     fc2_ms = timer.durations("fc1_end", "fc2_end")
     gate_ms = timer.durations("gate_begin", "gate_end")
     r = moe.deepspeed_moe.last_routing
-    rows_local = None
     if ep == 1:
         rows_local = int(r.expert_offsets[-1])               # kept (token, expert) pairs = GEMM rows this launch
+    else:
+        rows_local = moe.deepspeed_moe.last_ffn_rows         # rows received by this rank's experts (last step)
     fc1_avg = statistics.mean(fc1_ms) if fc1_ms else None
     roofline = None
     if fc1_avg and rows_local is not None:
-        flops = 2.0 * rows_local * (2 * I) * M                # algorithmic: gate+up projections over kept rows only
+        flops = 2.0 * rows_local * (2 * I) * M                # algorithmic: gate+up projections over kept rows only (rank 0)
         ach = flops / (fc1_avg * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "grouped_gemm_kernel<SWIGLU> (fc1 + SiLU*mul epilogue)",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
@@ -195,14 +202,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(state, experts)
         ms = elapsed / args.steps * 1e3
-        n_kept = (rows_local / S) if rows_local is not None else None
+        n_kept = float(r.expert_offsets[-1]) / S             # kept (token, expert) pairs per token on rank 0
         line = {
             "metric": "MoE-layer tokens/sec (top-2, 4 experts, StableLM-1.6B-4e block)",
             "value": world * S * args.steps / elapsed,
             "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU over gloo, timing meaningless)" if rehearsal else ""),
             "config": {"workload": f"BASELINE config 2: StableLM-1.6B-4e MoE block forward, d={M}, expert width {I} SwiGLU, "
                                    f"{E} experts top-{TOPK}, capacity factor {CF} (training capacity), 2nd-expert Gumbel "
                                    f"sampling on (upstream default), {args.batch} x ({N_IMG} img + {N_TXT} text) tokens per GPU",

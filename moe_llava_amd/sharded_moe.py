@@ -146,6 +146,8 @@ class MOELayer(nn.Module):
         self.l_aux: Optional[Tensor] = None
         self.exp_counts: Optional[Tensor] = None
         self.last_routing: Optional[ops.Routing] = None
+        #: rows the local grouped GEMM processed in the last expert-parallel forward (None when ep_size == 1)
+        self.last_ffn_rows: Optional[int] = None
         #: set to an ops.PhaseTimer to record HIP events around gate / fc1 / fc2 / combine (wall_clock_breakdown)
         self.timer: Optional[ops.PhaseTimer] = None
         self._warned_grad = False
@@ -208,6 +210,7 @@ class MOELayer(nn.Module):
         recv_mat = kept_h[:, me * El:(me + 1) * El]                  # [src, le] rows I receive
         recv_splits = recv_mat.sum(1).tolist()
         n_send, n_recv = int(sum(send_splits)), int(sum(recv_splits))
+        self.last_ffn_rows = n_recv
         send = ops.gather_rows(x, r.perm, 1, r.expert_offsets[E:E + 1], n_send)
         recv = torch.empty((max(n_recv, 1), M), dtype=torch.bfloat16, device=x.device)
         _all_to_all_rows(recv[:n_recv], send[:n_send], recv_splits, send_splits, self.ep_group)
