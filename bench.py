@@ -197,6 +197,18 @@ def main():
                     "fc2_tflops": (2.0 * rows_local * M * I / (statistics.mean(fc2_ms) * 1e-3) / 1e12) if fc2_ms else None,
                     "gate_routing_avg_ms": statistics.mean(gate_ms) if gate_ms else None}
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the bench, so they come from the
+    # committed summary of separate rocprofv3 --pmc passes over this same command (tools/profile_bench.sh ->
+    # tools/pmc_summary.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); null if absent or if
+    # the workload differs from the profiled one.
+    if roofline is not None and world == 1 and args.batch == BATCH:
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary_r01e.json")
+        if os.path.exists(pmc):
+            k = json.load(open(pmc)).get("void moe::grouped_gemm_kernel<1>", {})
+            if "hbm_bytes_per_launch" in k:
+                roofline["traffic"] = k["hbm_bytes_per_launch"]
+                roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, profiles/r01/pmc_summary_r01e.json)"
+                roofline["algorithmic_bytes"] = 2.0 * (2 * I * M * E) + 2.0 * S * M + 2.0 * rows_local * I
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

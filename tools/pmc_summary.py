@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs (one directory per pass) into profiles/<round>/pmc_summary.json.
+
+HBM traffic per launch follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE is in KiB and on gfx950 reports exactly
+half the bytes of wide coalesced reads (16 B/lane, LDS-DMA included) -> doubled; WRITE_SIZE (KiB) is exact for
+16-byte streaming stores.  usage: pmc_summary.py OUT.json DIR [DIR ...]"""
+import collections, csv, glob, json, os, sys
+
+out, dirs = sys.argv[1], sys.argv[2:]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for d in dirs:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+res = {}
+for k, cs in agg.items():
+    if "moe::" not in k:
+        continue
+    e = {c: sum(v) / len(v) for c, v in cs.items()}
+    e["launches_profiled"] = max(len(v) for v in cs.values())
+    if k in dur:
+        e["avg_duration_us_profiled"] = sum(dur[k]) / len(dur[k])
+    if "FETCH_SIZE" in e:
+        e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2      # gfx950 correction (x2)
+    if "WRITE_SIZE" in e:
+        e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024
+    if "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
+        e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+    if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e:
+        e["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
+    if "GRBM_GUI_ACTIVE" in e and "avg_duration_us_profiled" in e:
+        e["eff_clock_ghz"] = e["GRBM_GUI_ACTIVE"] / 8 / e["avg_duration_us_profiled"] / 1e3
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "GRBM_GUI_ACTIVE" in e:
+        e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8)   # 1024 SIMDs
+    res[k.split("(")[0]] = e
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print(json.dumps(res, indent=1, sort_keys=True))
