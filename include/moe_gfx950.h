@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 2
+#define MOE_ABI_VERSION 3
 
 /* activation / expert-MLP form of moe_expert_ffn_fwd */
 #define MOE_ACT_SWIGLU   0 /* h = silu(Wa x) * (Wb x); W1 = [Wa ; Wb] ([2I, M]).  StableLM: Wa=gate_proj, Wb=up_proj
@@ -138,6 +138,62 @@ int moe_gather_rows_fwd(const void *src, const int32_t *gather, int gather_shift
  * out [S,M] bf16 is fully overwritten.  M % 8 == 0.  top_k = 1 or 2 (columns of the [S,top_k] arrays). */
 int moe_combine_fwd(const void *y, const int32_t *expert_idx, const int32_t *slot, const float *weight,
                     const int32_t *expert_offsets, int S, int M, int top_k, void *out, void *stream);
+
+/* ---- backward ---------------------------------------------------------------
+ * Upstream has no hand-written backward: torch autograd differentiates top2gating, the two einsums, _AllToAll
+ * (whose backward is the same all-to-all on the gradients) and the expert nn.Linear modules.  The reference trains
+ * through it (moellava/train/train.py with scripts/v1/.../finetune_moe.sh; l_aux joins the loss at
+ * moellava/model/language_model/llava_stablelm_moe.py:461-472).  These entry points are the autograd of the forward
+ * entry points above, same buffers and index form. */
+
+/* moe_expert_ffn_fwd_train: moe_expert_ffn_fwd that also keeps the pre-activation output of the first Linear(s):
+ *   ab [max_rows, N1] bf16 (SWIGLU: columns [0,I) = Wa x, [I,2I) = Wb x; GELU_NEW: W1 x + b1), h [max_rows, I], y as
+ * above; h and y are bit-identical to moe_expert_ffn_fwd's.  Three launches. */
+int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
+                             const void *w1, const void *b1, const void *w2, const void *b2,
+                             const int32_t *group_offsets, int G, int n_experts_local, int max_rows,
+                             int M, int I, void *ab, void *h, void *y, void *stream);
+
+size_t moe_expert_ffn_bwd_workspace_bytes(int act, int G, int n_experts_local, int max_rows, int M, int I);
+
+/* moe_expert_ffn_bwd: gradients of moe_expert_ffn_fwd_train given dy [max_rows, M] bf16 (compact rows).
+ *   a, lda, gather, gather_shift, w1, w2, group_offsets, G, n_experts_local, max_rows, M, I: as in the forward call
+ *   ab, h        what the forward call kept
+ *   da_rows      [max_rows, M] bf16 out: gradient of every compact input row (dispatch backward sums them per token)
+ *   dw1 [n_experts_local, N1, M], dw2 [n_experts_local, M, I] bf16 out (fully overwritten, zeros for an idle expert)
+ *   db1 [n_experts_local, N1], db2 [n_experts_local, M] fp32 out, or NULL for bias-free experts
+ * G must be a multiple of n_experts_local (groups ordered (source rank, local expert) as in the forward pass).
+ * Four grouped-GEMM launches (two data gradients, two weight gradients) + transposes of the operands into
+ * K-contiguous images + the activation gradient; fixed launch count. */
+int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
+                       const void *w1, const void *w2, const void *ab, const void *h, const void *dy,
+                       const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
+                       void *da_rows, void *dw1, float *db1, void *dw2, float *db2,
+                       void *workspace, size_t ws_bytes, void *stream);
+
+/* moe_combine_bwd: backward of moe_combine_fwd.  dy[pos(s,j)] = bf16( float(bf16(w[s,j])) * dout[s] ) for every kept
+ * choice, dweight[s,j] = <dout[s], y[pos(s,j)]> in fp32 (0 for a dropped choice).  dy [max_rows, M] bf16,
+ * dweight [S, top_k] fp32. */
+int moe_combine_bwd(const void *dout, const void *y, const int32_t *expert_idx, const int32_t *slot, const float *weight,
+                    const int32_t *expert_offsets, int S, int M, int top_k, void *dy, float *dweight, void *stream);
+
+size_t moe_gate_bwd_workspace_bytes(int S, int M, int E);
+
+/* moe_gate_bwd: backward of moe_routing_top2_fwd + moe_gate_logits_fwd.
+ *   dweight [S,2] fp32 (from moe_combine_bwd), dl_aux device pointer to the gradient of l_aux (or NULL = 0)
+ *   dlogits [S,E] fp32 out: through the renormalisation g_j / clamp(g_1+g_2, eps), the post-drop masks, the
+ *           l_aux term E * ce[e] / S and the softmax (the argmax / capacity decisions carry no gradient)
+ *   dwg     [E,M] fp32 out = dlogits^T @ float(x)   (deterministic two-stage reduction)
+ * The gradient w.r.t. x through the gate is added by moe_dispatch_bwd. */
+int moe_gate_bwd(const void *x_bf16, const float *logits, const int32_t *expert_idx, const int32_t *slot,
+                 const float *dweight, const float *dl_aux, int S, int M, int E, float *dlogits, float *dwg,
+                 void *workspace, size_t ws_bytes, void *stream);
+
+/* moe_dispatch_bwd: dx[s] = bf16( sum_j da_rows[pos(s,j)] + sum_e dlogits[s,e] * wg[e] ), the backward of the dispatch
+ * einsum plus the gate's F.linear w.r.t. its input.  dlogits / wg may both be NULL (no gate term).  dx [S,M] bf16. */
+int moe_dispatch_bwd(const void *da_rows, const int32_t *expert_idx, const int32_t *slot, const int32_t *expert_offsets,
+                     const float *dlogits, const void *wg, int wg_is_bf16, int S, int M, int E, int top_k, void *dx,
+                     void *stream);
 
 #ifdef __cplusplus
 }

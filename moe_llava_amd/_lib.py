@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # MOE_GFX950_LIB points the loader at another build of the same ABI (kernel A/B experiments, tools/variants)
 LIB_PATH = os.environ.get("MOE_GFX950_LIB") or os.path.join(_PKG, "libmoe_gfx950.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # (name, restype, argtypes) -- must mirror include/moe_gfx950.h exactly
 _SIGNATURES = [
@@ -34,6 +34,23 @@ _SIGNATURES = [
     ("moe_gather_rows_fwd", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("moe_combine_fwd", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    # ---- backward ----
+    ("moe_expert_ffn_fwd_train", c_int,
+     [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("moe_expert_ffn_bwd_workspace_bytes", c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    ("moe_expert_ffn_bwd", c_int,
+     [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("moe_combine_bwd", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    ("moe_gate_bwd_workspace_bytes", c_size_t, [c_int, c_int, c_int]),
+    ("moe_gate_bwd", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+      c_size_t, c_void_p]),
+    ("moe_dispatch_bwd", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+      c_void_p]),
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]

@@ -1,0 +1,634 @@
+// Backward of the MoE block for gfx950: everything except the GEMMs themselves.
+//
+//   combine backward      dY[pos] = bf16(w) * dOut[s],  dweight[s,j] = <dOut[s], Y[pos]>        (einsum "sec,ecm->sm")
+//   routing backward      dweight, d l_aux -> dlogits through renormalisation, capacity mask and softmax (top2gating)
+//   gate backward         dwg = dlogits^T @ float(x)                                              (F.linear backward)
+//   dispatch backward     dx[s] = sum_j dXrows[pos(s,j)] + dlogits[s] @ wg                         (einsum "sec,sm->ecm")
+//   activation fwd / bwd  over the compact rows (training keeps the pre-activation fc1 output)
+//   transposes            K-contiguous operands for the dgrad / wgrad launches of the grouped NT GEMM
+//   bias gradient         per-expert column sums
+//
+// All kernels stream whole rows, 16 B per lane; they are HBM-bound.  Row counts that depend on the routing stay on
+// the device (group_offsets), grids are sized for the worst case.
+#include "moe_common.h"
+
+namespace moe {
+
+// ------------------------------------------------------------------------------------------------
+// activation forward / backward
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t *__restrict__ ab, const int *__restrict__ n_rows_dev,
+                                                      int max_rows, int I, bf16_t *__restrict__ h) {
+    int n = *n_rows_dev;
+    if (n > max_rows) n = max_rows;
+    const int chunks = I >> 3;
+    const long long total = (long long)n * chunks;
+    const int N1 = (ACT == MOE_ACT_SWIGLU) ? 2 * I : I;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long r = t / chunks;
+        const int c = (int)(t - r * chunks);
+        const bf16_t *row = ab + r * N1 + c * 8;
+        float a[8], o[8];
+        unpack8(*reinterpret_cast<const uint4 *>(row), a);
+        uint4 out;
+        if (ACT == MOE_ACT_SWIGLU) {
+            float b[8];
+            unpack8(*reinterpret_cast<const uint4 *>(row + I), b);
+            unsigned short hb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hb[i] = swiglu_bf16(a[i], b[i]);
+            out.x = hb[0] | ((unsigned)hb[1] << 16);
+            out.y = hb[2] | ((unsigned)hb[3] << 16);
+            out.z = hb[4] | ((unsigned)hb[5] << 16);
+            out.w = hb[6] | ((unsigned)hb[7] << 16);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = gelu_new_bf16(a[i]);
+            out = pack8(o);
+        }
+        *reinterpret_cast<uint4 *>(h + r * I + c * 8) = out;
+    }
+}
+
+// autograd of the bf16 graph: h = silu(a) * b  ->  db = g * silu(a), d silu = g * b, da = d silu * silu'(a)
+// (each product rounded to bf16 as the bf16 tensors of the reference's backward are)
+template <int ACT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t *__restrict__ ab, const bf16_t *__restrict__ dh,
+                                                      const int *__restrict__ n_rows_dev, int max_rows, int I,
+                                                      bf16_t *__restrict__ dab) {
+    int n = *n_rows_dev;
+    if (n > max_rows) n = max_rows;
+    const int chunks = I >> 3;
+    const long long total = (long long)n * chunks;
+    const int N1 = (ACT == MOE_ACT_SWIGLU) ? 2 * I : I;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long r = t / chunks;
+        const int c = (int)(t - r * chunks);
+        const bf16_t *row = ab + r * N1 + c * 8;
+        float a[8], g[8];
+        unpack8(*reinterpret_cast<const uint4 *>(row), a);
+        unpack8(*reinterpret_cast<const uint4 *>(dh + r * I + c * 8), g);
+        if (ACT == MOE_ACT_SWIGLU) {
+            float b[8], da[8], db[8];
+            unpack8(*reinterpret_cast<const uint4 *>(row + I), b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float sig = fast_sigmoid(a[i]);
+                const float sg = rbf(a[i] * sig);
+                db[i] = g[i] * sg;
+                const float dsg = rbf(g[i] * b[i]);
+                da[i] = dsg * (sig * (1.f + a[i] * (1.f - sig)));
+            }
+            *reinterpret_cast<uint4 *>(dab + r * N1 + c * 8) = pack8(da);
+            *reinterpret_cast<uint4 *>(dab + r * N1 + I + c * 8) = pack8(db);
+        } else {
+            float dx[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x = a[i];
+                const float k = 0.7978845608028654f;
+                const float u = k * (x + 0.044715f * x * x * x);
+                const float th = fast_tanh(u);
+                const float d = 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k * (1.f + 3.f * 0.044715f * x * x);
+                dx[i] = g[i] * d;
+            }
+            *reinterpret_cast<uint4 *>(dab + r * N1 + c * 8) = pack8(dx);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// combine backward: one wave per token
+// ------------------------------------------------------------------------------------------------
+template <int TOPK>
+__global__ __launch_bounds__(256) void combine_bwd_kernel(const bf16_t *__restrict__ dout, const bf16_t *__restrict__ y,
+                                                          const int *__restrict__ expert_idx, const int *__restrict__ slot,
+                                                          const float *__restrict__ weight,
+                                                          const int *__restrict__ expert_offsets, int S, int M,
+                                                          bf16_t *__restrict__ dy, float *__restrict__ dweight) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = M >> 3;
+    for (int s = blockIdx.x * 4 + wave; s < S; s += gridDim.x * 4) {
+        long long pos[TOPK];
+        float w[TOPK], dot[TOPK];
+        bool on[TOPK];
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) {
+            const int sl = slot[s * TOPK + j];
+            on[j] = sl >= 0;
+            w[j] = rbf(weight[s * TOPK + j]);  // combine_weights.type_as(x)
+            pos[j] = on[j] ? (long long)(expert_offsets[expert_idx[s * TOPK + j]] + sl) : 0;
+            dot[j] = 0.f;
+        }
+        const uint4 *gp = reinterpret_cast<const uint4 *>(dout + (long long)s * M);
+        for (int c = lane; c < chunks; c += 64) {
+            float g[8];
+            unpack8(gp[c], g);
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j) {
+                if (on[j]) {
+                    float yv[8], o[8];
+                    unpack8(reinterpret_cast<const uint4 *>(y + pos[j] * M)[c], yv);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        dot[j] += g[i] * yv[i];
+                        o[i] = w[j] * g[i];
+                    }
+                    reinterpret_cast<uint4 *>(dy + pos[j] * M)[c] = pack8(o);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) {
+            float d = dot[j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            if (lane == 0) dweight[s * TOPK + j] = on[j] ? d : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// routing backward (top-2): dweight [S,2], d l_aux -> dlogits [S,E]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void first_choice_hist_kernel(const int *__restrict__ expert_idx, int S, int E, int topk,
+                                                                int *__restrict__ n1) {
+    __shared__ int h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) atomicAdd(&h[expert_idx[s * topk]], 1);
+    __syncthreads();
+    if (threadIdx.x < E && h[threadIdx.x]) atomicAdd(&n1[threadIdx.x], h[threadIdx.x]);
+}
+
+template <int EMAX>
+__global__ __launch_bounds__(256) void routing_top2_bwd_kernel(const float *__restrict__ logits,
+                                                               const int *__restrict__ expert_idx,
+                                                               const int *__restrict__ slot,
+                                                               const float *__restrict__ dweight,
+                                                               const float *__restrict__ dl_aux, const int *__restrict__ n1,
+                                                               int S, int E, float *__restrict__ dlogits) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    float g[EMAX], dg[EMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        g[e] = e < E ? logits[(long long)s * E + e] : -INFINITY;
+        mx = fmaxf(mx, g[e]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        g[e] = e < E ? expf(g[e] - mx) : 0.f;
+        sum += g[e];
+    }
+    const float inv = 1.f / sum;
+    // l_aux = E * sum_e me[e] * ce[e], me = mean_s gates, ce = n1 / S (constant)  ->  d gates[s,e] = dl * E * ce[e] / S
+    const float dl = dl_aux ? *dl_aux : 0.f;
+    const float la = dl * (float)E / ((float)S * (float)S);
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        g[e] *= inv;
+        dg[e] = e < E ? la * (float)n1[e] : 0.f;
+    }
+    const int i1 = expert_idx[s * 2], i2 = expert_idx[s * 2 + 1];
+    const bool k1 = slot[s * 2] >= 0, k2 = slot[s * 2 + 1] >= 0;
+    float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        if (e == i1 && k1) g1 = g[e];
+        if (e == i2 && k2) g2 = g[e];
+    }
+    const float dw1 = dweight[s * 2], dw2 = dweight[s * 2 + 1];
+    const float dsum = g1 + g2;
+    const float eps = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+    float dg1, dg2;
+    if (dsum >= eps) {  // clamp(min=eps) passes the gradient where it does not clamp
+        const float den = dsum;
+        const float t = (dw1 * g1 + dw2 * g2) / den;
+        dg1 = (dw1 - t) / den;
+        dg2 = (dw2 - t) / den;
+    } else {
+        dg1 = dw1 / eps;
+        dg2 = dw2 / eps;
+    }
+    float dotp = 0.f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        if (e == i1 && k1) dg[e] += dg1;
+        if (e == i2 && k2) dg[e] += dg2;
+        dotp += g[e] * dg[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e)
+        if (e < E) dlogits[(long long)s * E + e] = g[e] * (dg[e] - dotp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gate weight gradient: dwg[e,m] = sum_s dlogits[s,e] * float(x[s,m]); two deterministic stages
+// ------------------------------------------------------------------------------------------------
+template <int EC>
+__global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const bf16_t *__restrict__ x, const float *__restrict__ dlogits,
+                                                                 int S, int M, int E, int rows_per_chunk,
+                                                                 float *__restrict__ partial) {
+    const int col0 = blockIdx.y * 2048 + threadIdx.x * 8;
+    if (col0 >= M) return;
+    const int e0 = blockIdx.z * EC;
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(S, r0 + rows_per_chunk);
+    float acc[EC][8];
+#pragma unroll
+    for (int e = 0; e < EC; ++e)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[e][i] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        float xv[8];
+        unpack8(*reinterpret_cast<const uint4 *>(x + (long long)r * M + col0), xv);
+#pragma unroll
+        for (int e = 0; e < EC; ++e) {
+            const float d = (e0 + e < E) ? dlogits[(long long)r * E + e0 + e] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[e][i] += d * xv[i];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EC; ++e) {
+        if (e0 + e < E) {
+            float *o = partial + ((long long)blockIdx.x * E + e0 + e) * M + col0;
+            *reinterpret_cast<float4 *>(o) = make_float4(acc[e][0], acc[e][1], acc[e][2], acc[e][3]);
+            *reinterpret_cast<float4 *>(o + 4) = make_float4(acc[e][4], acc[e][5], acc[e][6], acc[e][7]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gate_wgrad_reduce_kernel(const float *__restrict__ partial, int nchunks, long long EM,
+                                                                float *__restrict__ dwg) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= EM) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < nchunks; ++c) {
+        const float4 v = *reinterpret_cast<const float4 *>(partial + (long long)c * EM + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(dwg + i) = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch backward: one wave per token
+// ------------------------------------------------------------------------------------------------
+template <int TOPK, bool WG_BF16>
+__global__ __launch_bounds__(256) void dispatch_bwd_kernel(const bf16_t *__restrict__ da_rows, const int *__restrict__ expert_idx,
+                                                           const int *__restrict__ slot, const int *__restrict__ expert_offsets,
+                                                           const float *__restrict__ dlogits, const void *__restrict__ wg,
+                                                           int S, int M, int E, bf16_t *__restrict__ dx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = M >> 3;
+    for (int s = blockIdx.x * 4 + wave; s < S; s += gridDim.x * 4) {
+        const uint4 *src[TOPK];
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) {
+            const int sl = slot[s * TOPK + j];
+            src[j] = sl >= 0 ? reinterpret_cast<const uint4 *>(
+                                   da_rows + (long long)(expert_offsets[expert_idx[s * TOPK + j]] + sl) * M)
+                             : nullptr;
+        }
+        for (int c = lane; c < chunks; c += 64) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j) {
+                if (src[j]) {
+                    float v[8];
+                    unpack8(src[j][c], v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += v[i];
+                }
+            }
+            if (dlogits) {
+                for (int e = 0; e < E; ++e) {
+                    const float d = dlogits[(long long)s * E + e];
+                    float wv[8];
+                    if (WG_BF16) {
+                        unpack8(*reinterpret_cast<const uint4 *>((const bf16_t *)wg + (long long)e * M + c * 8), wv);
+                    } else {
+                        const float4 a = *reinterpret_cast<const float4 *>((const float *)wg + (long long)e * M + c * 8);
+                        const float4 b = *reinterpret_cast<const float4 *>((const float *)wg + (long long)e * M + c * 8 + 4);
+                        wv[0] = a.x; wv[1] = a.y; wv[2] = a.z; wv[3] = a.w;
+                        wv[4] = b.x; wv[5] = b.y; wv[6] = b.z; wv[7] = b.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += d * wv[i];
+                }
+            }
+            reinterpret_cast<uint4 *>(dx + (long long)s * M)[c] = pack8(acc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// transposes: rows of group g -> K range [k_group[g], k_group[g] + roundup64(rows_g)) of a [C, ldk] image
+// ------------------------------------------------------------------------------------------------
+__global__ void k_offsets_kernel(const int *__restrict__ group_offsets, int G, int El, int *__restrict__ k_group,
+                                 int *__restrict__ k_expert) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int per = G / El;  // groups per local expert (ep sources)
+    int acc = 0;
+    for (int q = 0; q < G; ++q) {
+        const int le = q / per, src = q - le * per;
+        const int g = src * El + le;
+        if (src == 0) k_expert[le] = acc;
+        k_group[g] = acc;
+        const int rows = group_offsets[g + 1] - group_offsets[g];
+        acc += (rows + 63) & ~63;
+    }
+    k_expert[El] = acc;
+}
+
+constexpr int TR = 128;      // rows (K) per transpose tile
+constexpr int TC = 64;       // columns per transpose tile
+constexpr int TPITCH = 72;   // LDS row pitch in elements (144 B: 16-byte aligned rows)
+
+// uniform_rows > 0: batched plain transpose (group b = rows [b*R, (b+1)*R), destination image b at dst + b*C*R, ldk = R)
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const bf16_t *__restrict__ src, long long lds_,
+                                                             const int *__restrict__ gather, int gather_shift,
+                                                             const int *__restrict__ group_offsets, int G,
+                                                             const int *__restrict__ k_group, int uniform_rows, int C,
+                                                             bf16_t *__restrict__ dst, long long ldk) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[TR * TPITCH];
+    const int rt = blockIdx.x;
+    int rb = 0, re = 0, k0 = 0;
+    long long kbase = 0;
+    bool found = false;
+    if (uniform_rows > 0) {
+        const int tpg = (uniform_rows + TR - 1) / TR;
+        const int g = rt / tpg;
+        if (g < G) {
+            found = true;
+            rb = g * uniform_rows;
+            re = rb + uniform_rows;
+            k0 = (rt - g * tpg) * TR;
+            kbase = (long long)g * C * uniform_rows;
+        }
+    } else {
+        int tile0 = 0;
+        for (int g = 0; g < G; ++g) {
+            const int b = group_offsets[g], e = group_offsets[g + 1];
+            const int padded = (e - b + 63) & ~63;
+            const int nt = (padded + TR - 1) / TR;
+            if (rt < tile0 + nt) {
+                found = true;
+                rb = b;
+                re = e;
+                k0 = (rt - tile0) * TR;
+                kbase = k_group[g];
+                break;
+            }
+            tile0 += nt;
+        }
+    }
+    if (!found) return;
+    const int padded = (re - rb + 63) & ~63;
+    const int c0 = blockIdx.y * TC;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + i * 256;
+        const int row = q >> 3, ch = q & 7;
+        const int r = rb + k0 + row;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r < re && c0 + ch * 8 < C) {
+            const long long srow = gather ? (long long)(gather[r] >> gather_shift) : (long long)r;
+            v = *reinterpret_cast<const uint4 *>(src + srow * lds_ + c0 + ch * 8);
+        }
+        *reinterpret_cast<uint4 *>(tile + row * TPITCH + ch * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + i * 256;
+        const int c = q >> 4, kc = q & 15;
+        if (k0 + kc * 8 < padded && c0 + c < C) {
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = tile[(kc * 8 + j) * TPITCH + c];
+            uint4 o;
+            o.x = e[0] | ((unsigned)e[1] << 16);
+            o.y = e[2] | ((unsigned)e[3] << 16);
+            o.z = e[4] | ((unsigned)e[5] << 16);
+            o.w = e[6] | ((unsigned)e[7] << 16);
+            *reinterpret_cast<uint4 *>(dst + kbase + (long long)(c0 + c) * ldk + k0 + kc * 8) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bias gradient: per-expert column sums of a compact-row matrix (fp32 hardware atomics into a zeroed buffer)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t *__restrict__ d, const int *__restrict__ group_offsets,
+                                                        int G, int El, int N, float *__restrict__ out) {
+    const int col0 = blockIdx.y * 2048 + threadIdx.x * 8;
+    if (col0 >= N) return;
+    const int n_rows = group_offsets[G];
+    const int r0 = blockIdx.x * 128;
+    const int r1 = min(n_rows, r0 + 128);
+    if (r0 >= r1) return;
+    int g = 0;
+    while (g < G - 1 && group_offsets[g + 1] <= r0) ++g;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        if (r >= group_offsets[g + 1]) {
+            float *o = out + (long long)(g % El) * N + col0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                unsafeAtomicAdd(o + i, acc[i]);
+                acc[i] = 0.f;
+            }
+            while (g < G - 1 && group_offsets[g + 1] <= r) ++g;
+        }
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4 *>(d + (long long)r * N + col0), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+    float *o = out + (long long)(g % El) * N + col0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) unsafeAtomicAdd(o + i, acc[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers shared with moe_gemm.hip
+// ------------------------------------------------------------------------------------------------
+static inline int ew_grid(long long items) {
+    long long b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b > 65536 ? 65536 : b);
+}
+
+int launch_k_offsets(const int *group_offsets, int G, int El, int *k_group, int *k_expert, hipStream_t st) {
+    hipLaunchKernelGGL(k_offsets_kernel, dim3(1), dim3(64), 0, st, group_offsets, G, El, k_group, k_expert);
+    return check_launch("k_offsets_kernel");
+}
+
+int launch_transpose_rows(const bf16_t *src, long long lds_, const int *gather, int gather_shift, const int *group_offsets,
+                          int G, const int *k_group, int max_rows, int C, bf16_t *dst, long long ldk, hipStream_t st) {
+    const int tiles = (max_rows + 64 * G) / TR + G;
+    dim3 grid(tiles, (C + TC - 1) / TC);
+    hipLaunchKernelGGL(transpose_rows_kernel, grid, dim3(256), 0, st, src, lds_, gather, gather_shift, group_offsets, G, k_group,
+                       0, C, dst, ldk);
+    return check_launch("transpose_rows_kernel");
+}
+
+int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst, hipStream_t st) {
+    dim3 grid(B * ((R + TR - 1) / TR), (C + TC - 1) / TC);
+    hipLaunchKernelGGL(transpose_rows_kernel, grid, dim3(256), 0, st, src, (long long)C, (const int *)nullptr, 0,
+                       (const int *)nullptr, B, (const int *)nullptr, R, C, dst, (long long)R);
+    return check_launch("transpose_rows_kernel(batched)");
+}
+
+int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, bf16_t *h, hipStream_t st) {
+    const int grid = ew_grid((long long)max_rows * (I >> 3));
+    if (act == MOE_ACT_SWIGLU)
+        hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_SWIGLU>), dim3(grid), dim3(256), 0, st, ab, n_rows_dev, max_rows, I, h);
+    else
+        hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_GELU_NEW>), dim3(grid), dim3(256), 0, st, ab, n_rows_dev, max_rows, I, h);
+    return check_launch("act_fwd_kernel");
+}
+
+int launch_act_bwd(int act, const bf16_t *ab, const bf16_t *dh, const int *n_rows_dev, int max_rows, int I, bf16_t *dab,
+                   hipStream_t st) {
+    const int grid = ew_grid((long long)max_rows * (I >> 3));
+    if (act == MOE_ACT_SWIGLU)
+        hipLaunchKernelGGL((act_bwd_kernel<MOE_ACT_SWIGLU>), dim3(grid), dim3(256), 0, st, ab, dh, n_rows_dev, max_rows, I, dab);
+    else
+        hipLaunchKernelGGL((act_bwd_kernel<MOE_ACT_GELU_NEW>), dim3(grid), dim3(256), 0, st, ab, dh, n_rows_dev, max_rows, I,
+                           dab);
+    return check_launch("act_bwd_kernel");
+}
+
+int launch_bias_grad(const bf16_t *d, const int *group_offsets, int G, int El, int max_rows, int N, float *out,
+                     hipStream_t st) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)El * N, st);
+    if (e != hipSuccess) return fail((int)e, "bias_grad memset: %s", hipGetErrorString(e));
+    if (max_rows == 0) return 0;
+    dim3 grid((max_rows + 127) / 128, (N + 2047) / 2048);
+    hipLaunchKernelGGL(bias_grad_kernel, grid, dim3(256), 0, st, d, group_offsets, G, El, N, out);
+    return check_launch("bias_grad_kernel");
+}
+
+static inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace moe
+
+using namespace moe;
+
+extern "C" int moe_combine_bwd(const void *dout, const void *y, const int32_t *expert_idx, const int32_t *slot,
+                               const float *weight, const int32_t *expert_offsets, int S, int M, int top_k, void *dy,
+                               float *dweight, void *stream) {
+    if (!dout || !y || !expert_idx || !slot || !weight || !expert_offsets || !dy || !dweight)
+        return fail(MOE_ERR_ARG, "moe_combine_bwd: null pointer");
+    if (S < 0 || M <= 0 || (M & 7) || (top_k != 1 && top_k != 2))
+        return fail(MOE_ERR_SHAPE, "moe_combine_bwd: need M%%8==0 and top_k in {1,2}");
+    if (!aligned16(dout) || !aligned16(y) || !aligned16(dy)) return fail(MOE_ERR_ALIGN, "moe_combine_bwd: 16-byte alignment");
+    if (S == 0) return 0;
+    const int grid = (S + 3) / 4 < 16384 ? (S + 3) / 4 : 16384;
+    hipStream_t st = (hipStream_t)stream;
+    if (top_k == 2)
+        hipLaunchKernelGGL((combine_bwd_kernel<2>), dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, (const bf16_t *)y,
+                           expert_idx, slot, weight, expert_offsets, S, M, (bf16_t *)dy, dweight);
+    else
+        hipLaunchKernelGGL((combine_bwd_kernel<1>), dim3(grid), dim3(256), 0, st, (const bf16_t *)dout, (const bf16_t *)y,
+                           expert_idx, slot, weight, expert_offsets, S, M, (bf16_t *)dy, dweight);
+    return check_launch("combine_bwd_kernel");
+}
+
+static inline int gate_rows_per_chunk(int S) {
+    int rpc = (S + 511) / 512;
+    return rpc < 64 ? 64 : rpc;
+}
+
+extern "C" size_t moe_gate_bwd_workspace_bytes(int S, int M, int E) {
+    if (S < 1 || M < 1 || E < 1) return 0;
+    const int rpc = gate_rows_per_chunk(S);
+    const size_t nchunks = (size_t)(S + rpc - 1) / rpc;
+    return pad256(sizeof(int) * 64) + pad256(sizeof(float) * nchunks * E * M);
+}
+
+extern "C" int moe_gate_bwd(const void *x, const float *logits, const int32_t *expert_idx, const int32_t *slot,
+                            const float *dweight, const float *dl_aux, int S, int M, int E, float *dlogits, float *dwg,
+                            void *workspace, size_t ws_bytes, void *stream) {
+    if (!x || !logits || !expert_idx || !slot || !dweight || !dlogits || !dwg || !workspace)
+        return fail(MOE_ERR_ARG, "moe_gate_bwd: null pointer");
+    if (S < 1 || M <= 0 || (M & 7) || E < 2 || E > 64)
+        return fail(MOE_ERR_SHAPE, "moe_gate_bwd: need S>=1, M%%8==0, 2<=E<=64 (S=%d M=%d E=%d)", S, M, E);
+    if (!aligned16(x) || !aligned16(dwg) || !aligned16(workspace))
+        return fail(MOE_ERR_ALIGN, "moe_gate_bwd: x / dwg / workspace not 16-byte aligned");
+    const size_t need = moe_gate_bwd_workspace_bytes(S, M, E);
+    if (ws_bytes < need) return fail(MOE_ERR_WORKSPACE, "moe_gate_bwd: workspace %zu < %zu bytes", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    int *n1 = reinterpret_cast<int *>(workspace);
+    float *partial = reinterpret_cast<float *>((char *)workspace + pad256(sizeof(int) * 64));
+    hipError_t e = hipMemsetAsync(n1, 0, sizeof(int) * 64, st);
+    if (e != hipSuccess) return fail((int)e, "moe_gate_bwd memset: %s", hipGetErrorString(e));
+    const int hb = (S + 255) / 256 < 1024 ? (S + 255) / 256 : 1024;
+    hipLaunchKernelGGL(first_choice_hist_kernel, dim3(hb), dim3(256), 0, st, expert_idx, S, E, 2, n1);
+    int rc = check_launch("first_choice_hist_kernel");
+    if (rc) return rc;
+    const dim3 grid((S + 255) / 256);
+#define LAUNCH_RB(EM)                                                                                                  \
+    hipLaunchKernelGGL((routing_top2_bwd_kernel<EM>), grid, dim3(256), 0, st, logits, expert_idx, slot, dweight, dl_aux, n1, \
+                       S, E, dlogits)
+    if (E <= 4) LAUNCH_RB(4);
+    else if (E <= 8) LAUNCH_RB(8);
+    else if (E <= 16) LAUNCH_RB(16);
+    else LAUNCH_RB(64);
+#undef LAUNCH_RB
+    rc = check_launch("routing_top2_bwd_kernel");
+    if (rc) return rc;
+    const int rpc = gate_rows_per_chunk(S);
+    const int nchunks = (S + rpc - 1) / rpc;
+    if (E <= 4) {
+        hipLaunchKernelGGL((gate_wgrad_partial_kernel<4>), dim3(nchunks, (M + 2047) / 2048, 1), dim3(256), 0, st,
+                           (const bf16_t *)x, dlogits, S, M, E, rpc, partial);
+    } else {
+        hipLaunchKernelGGL((gate_wgrad_partial_kernel<8>), dim3(nchunks, (M + 2047) / 2048, (E + 7) / 8), dim3(256), 0, st,
+                           (const bf16_t *)x, dlogits, S, M, E, rpc, partial);
+    }
+    rc = check_launch("gate_wgrad_partial_kernel");
+    if (rc) return rc;
+    const long long EM = (long long)E * M;
+    hipLaunchKernelGGL(gate_wgrad_reduce_kernel, dim3((unsigned)((EM / 4 + 255) / 256)), dim3(256), 0, st, partial, nchunks, EM,
+                       dwg);
+    return check_launch("gate_wgrad_reduce_kernel");
+}
+
+extern "C" int moe_dispatch_bwd(const void *da_rows, const int32_t *expert_idx, const int32_t *slot,
+                                const int32_t *expert_offsets, const float *dlogits, const void *wg, int wg_is_bf16, int S,
+                                int M, int E, int top_k, void *dx, void *stream) {
+    if (!da_rows || !expert_idx || !slot || !expert_offsets || !dx) return fail(MOE_ERR_ARG, "moe_dispatch_bwd: null pointer");
+    if ((dlogits != nullptr) != (wg != nullptr))
+        return fail(MOE_ERR_ARG, "moe_dispatch_bwd: dlogits and wg must be given together");
+    if (S < 0 || M <= 0 || (M & 7) || (top_k != 1 && top_k != 2) || E < 1 || E > 64)
+        return fail(MOE_ERR_SHAPE, "moe_dispatch_bwd: need M%%8==0, top_k in {1,2}, 1<=E<=64");
+    if (!aligned16(da_rows) || !aligned16(dx) || (wg && !aligned16(wg)))
+        return fail(MOE_ERR_ALIGN, "moe_dispatch_bwd: 16-byte alignment");
+    if (S == 0) return 0;
+    const int grid = (S + 3) / 4 < 16384 ? (S + 3) / 4 : 16384;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_DB(TK, BF)                                                                                             \
+    hipLaunchKernelGGL((dispatch_bwd_kernel<TK, BF>), dim3(grid), dim3(256), 0, st, (const bf16_t *)da_rows, expert_idx, \
+                       slot, expert_offsets, dlogits, wg, S, M, E, (bf16_t *)dx)
+    if (top_k == 2) {
+        if (wg_is_bf16) LAUNCH_DB(2, true);
+        else LAUNCH_DB(2, false);
+    } else {
+        if (wg_is_bf16) LAUNCH_DB(1, true);
+        else LAUNCH_DB(1, false);
+    }
+#undef LAUNCH_DB
+    return check_launch("dispatch_bwd_kernel");
+}

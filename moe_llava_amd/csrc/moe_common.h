@@ -38,4 +38,63 @@ __device__ __forceinline__ float bf2f(bf16_t b) {
 // round an fp32 value to the nearest bf16 and return it as fp32
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+__device__ __forceinline__ void unpack8(const uint4 v, float *f) {
+    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, u[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, u[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float *f) {
+    uint4 o;
+    o.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
+    o.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+    o.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
+    o.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+    return o;
+}
+
+// ---- expert activations, evaluated the way a bf16 tensor goes through the reference's modules ----
+__device__ __forceinline__ float fast_sigmoid(float a) { return __builtin_amdgcn_rcpf(1.f + __expf(-a)); }
+__device__ __forceinline__ float fast_silu(float a) {
+    // a / (1 + exp(-a)); the result is rounded to bf16 right after, v_exp/v_rcp precision is ample
+    return a * fast_sigmoid(a);
+}
+__device__ __forceinline__ float fast_tanh(float u) {
+    // tanh(u) = 1 - 2 / (1 + exp(2u)); saturates correctly for |u| large
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * u));
+}
+// SwiGLU on bf16 outputs a, b of the two fc1 Linears: silu rounds to bf16, then the product does
+// (stablelm/modeling_stablelm_epoch.py:167-168, qwen/modeling_qwen.py:601-606)
+__device__ __forceinline__ bf16_t swiglu_bf16(float a, float b) { return f2bf(rbf(fast_silu(a)) * b); }
+// HF NewGELUActivation evaluated the way a bf16 tensor goes through it: every elementwise op rounds to bf16
+// (phi/modeling_phi.py:207,213 with hidden_act "gelu_new", phi/configuration_phi.py:128).
+__device__ __forceinline__ float gelu_new_bf16(float x) {
+    const float p3 = rbf(x * x * x);
+    const float t1 = rbf(0.044715f * p3);
+    const float t2 = rbf(x + t1);
+    const float t3 = rbf(0.7978845608028654f * t2);
+    const float t4 = rbf(fast_tanh(t3));
+    const float t5 = rbf(1.0f + t4);
+    const float t6 = rbf(0.5f * x);
+    return rbf(t6 * t5);
+}
+
+// ---- helpers of the backward pass implemented in moe_backward.hip, used by moe_expert_ffn_bwd ----
+// K-order layout of the transposed activations: group g = (src, le) goes to K slot le*(G/El)+src, every group padded
+// with zeros to a multiple of 64 rows; k_group[g] = first K index of group g, k_expert[le] = first K index of expert le.
+int launch_k_offsets(const int *group_offsets, int G, int n_experts_local, int *k_group, int *k_expert, hipStream_t st);
+// dst[c, k_group[g] + (r - group_offsets[g])] = src[row(r), c] for the rows of every group, zero padding included.
+int launch_transpose_rows(const bf16_t *src, long long lds, const int *gather, int gather_shift, const int *group_offsets,
+                          int G, const int *k_group, int max_rows, int C, bf16_t *dst, long long ldk, hipStream_t st);
+// dst[b, c, r] = src[b, r, c]
+int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst, hipStream_t st);
+int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, bf16_t *h, hipStream_t st);
+int launch_act_bwd(int act, const bf16_t *ab, const bf16_t *dh, const int *n_rows_dev, int max_rows, int I, bf16_t *dab,
+                   hipStream_t st);
+// out[e, n] = sum over the rows of expert e's groups of d[r, n]  (fp32, zeroed here)
+int launch_bias_grad(const bf16_t *d, const int *group_offsets, int G, int n_experts_local, int max_rows, int N, float *out,
+                     hipStream_t st);
+
 }  // namespace moe

@@ -59,6 +59,11 @@ struct GemmParams {
     int b_row_offset;  // gated: W row of the first 'b' projection row (= I)
     int max_row_tiles;
     int col_tiles;
+    // weight-gradient mode (k_offsets != nullptr): group g is expert g with rows_per_group output rows; both operands
+    // are K-contiguous transposed images and expert g contracts over K range [k_offsets[g], k_offsets[g+1])
+    long long ldw;         // row stride of W (= K in the forward layout)
+    const int *k_offsets;
+    int rows_per_group;
 };
 
 __device__ __forceinline__ void glds16(const bf16_t *gsrc, bf16_t *lds_wave_base) {
@@ -67,27 +72,6 @@ __device__ __forceinline__ void glds16(const bf16_t *gsrc, bf16_t *lds_wave_base
         reinterpret_cast<__attribute__((address_space(3))) void *>(
             static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_wave_base))),
         16, 0, GEMM_AUX);
-}
-
-__device__ __forceinline__ float fast_silu(float a) {
-    // a / (1 + exp(-a)); the result is rounded to bf16 right after, v_exp/v_rcp precision is ample
-    return a * __builtin_amdgcn_rcpf(1.f + __expf(-a));
-}
-__device__ __forceinline__ float fast_tanh(float u) {
-    // tanh(u) = 1 - 2 / (1 + exp(2u)); saturates correctly for |u| large
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * u));
-}
-// HF NewGELUActivation evaluated the way a bf16 tensor goes through it: every elementwise op rounds to bf16
-// (phi/modeling_phi.py:207,213 with hidden_act "gelu_new", phi/configuration_phi.py:128).
-__device__ __forceinline__ float gelu_new_bf16(float x) {
-    const float p3 = rbf(x * x * x);
-    const float t1 = rbf(0.044715f * p3);
-    const float t2 = rbf(x + t1);
-    const float t3 = rbf(0.7978845608028654f * t2);
-    const float t4 = rbf(fast_tanh(t3));
-    const float t5 = rbf(1.0f + t4);
-    const float t6 = rbf(0.5f * x);
-    return rbf(t6 * t5);
 }
 
 // LDS: a ring of NS slots, each one K slice of BK: X tile [256][BK] bf16 + W tile [256][BK] bf16.
@@ -143,7 +127,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 
     // ---- row tile -> group (expert), row range ----
     int row_begin = 0, row_end = 0, grp = -1;
-    {
+    if (p.k_offsets) {
+        const int tpg = (p.rows_per_group + BM - 1) / BM;
+        const int g = rt / tpg;
+        if (g < p.G) {
+            grp = g;
+            row_begin = g * p.rows_per_group + (rt - g * tpg) * BM;
+            row_end = (g + 1) * p.rows_per_group;
+        }
+    } else {
         int tile0 = 0;
         for (int g = 0; g < p.G; ++g) {
             const int b = p.group_offsets[g], e = p.group_offsets[g + 1];
@@ -159,7 +151,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     }
     if (grp < 0) return;  // surplus block of the worst-case grid (uniform per block)
     const int expert = grp % p.n_experts;
-    const bf16_t *wbase = p.w + (long long)expert * p.w_expert_stride;
+    const int k_first = p.k_offsets ? p.k_offsets[grp] : 0;
+    const bf16_t *wbase = p.w + (long long)expert * p.w_expert_stride + k_first;
+    const bf16_t *abase = p.a + k_first;
+    const int a_row0 = p.k_offsets ? grp * p.rows_per_group : 0;  // wgrad: A rows are local to the expert
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -191,8 +186,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             const int cs = c ^ xsw(row);
             int prow = row_begin + row;
             if (prow > row_end - 1) prow = row_end - 1;  // clamp: rows past the group end are never stored
-            const long long srow = p.gather ? (long long)(p.gather[prow] >> p.gather_shift) : (long long)prow;
-            a_src[j] = p.a + srow * p.lda + cs * 8;
+            const long long srow = p.gather ? (long long)(p.gather[prow] >> p.gather_shift) : (long long)(prow - a_row0);
+            a_src[j] = abase + srow * p.lda + cs * 8;
             int wrow;
             if (EPI == EPI_SWIGLU) {
                 const int col = ct * (BNW / 2) + (row >> 6) * 32 + (row & 31);
@@ -200,7 +195,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             } else {
                 wrow = min(ct * BNW + row, p.N_out - 1);
             }
-            w_src[j] = wbase + (long long)wrow * p.K + cs * 8;
+            w_src[j] = wbase + (long long)wrow * p.ldw + cs * 8;
         }
     }
     bf16_t *const lds_e = reinterpret_cast<bf16_t *>(lds);
@@ -229,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf) acc[nf][mf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;  // >= 1 (K % 64 == 0)
+    const int nk = p.k_offsets ? (p.k_offsets[grp + 1] - k_first) / BK : p.K / BK;  // K % 64 == 0; wgrad: may be 0
     // K loop: ring of NS slots, NS-1 K slices of LDS-DMA in flight behind the one being consumed, one counted
     // vmcnt + raw s_barrier per slice.  At step kt the slices issued behind kt are min(NS-2, nk-1-kt), 2*NP LDS-DMA
     // pieces per wave each.  (Measured: one barrier per 64 of K with 2 slots beats 32 of K with 4 or 5 slots.)
@@ -441,6 +436,9 @@ extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, co
     p.K = K;
     p.N_out = N;
     p.b_row_offset = N;
+    p.ldw = K;
+    p.k_offsets = nullptr;
+    p.rows_per_group = 0;
     p.max_row_tiles = max_rows / BM + G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
     hipStream_t st = (hipStream_t)stream;
     if (epilogue == MOE_EPI_SWIGLU) {
@@ -472,4 +470,146 @@ extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int
     if (rc) return rc;
     return moe_grouped_gemm_fwd(MOE_EPI_PLAIN, h_ws, I, nullptr, 0, w2, b2, group_offsets, G, n_experts_local, max_rows, I, M,
                                 y, M, stream);
+}
+
+// out[e] ([R, N] bf16) = A_t[:, Ke] @ W_t[:, Ke]^T with Ke = [k_offsets[e], k_offsets[e+1]): the weight gradient of one
+// Linear for every local expert, both operands as K-contiguous transposed images of row stride ldk.
+static int launch_wgrad(const bf16_t *a_t, const bf16_t *w_t, long long ldk, const int *k_offsets, int n_experts, int R, int N,
+                        bf16_t *out, hipStream_t st) {
+    GemmParams p;
+    p.a = a_t;
+    p.lda = ldk;
+    p.gather = nullptr;
+    p.gather_shift = 0;
+    p.w = w_t;
+    p.w_expert_stride = 0;
+    p.bias = nullptr;
+    p.bias_expert_stride = 0;
+    p.group_offsets = nullptr;
+    p.G = n_experts;
+    p.n_experts = n_experts;
+    p.out = out;
+    p.ldo = N;
+    p.K = 0;
+    p.N_out = N;
+    p.b_row_offset = N;
+    p.ldw = ldk;
+    p.k_offsets = k_offsets;
+    p.rows_per_group = R;
+    p.max_row_tiles = n_experts * ((R + BM - 1) / BM);
+    p.col_tiles = (N + BNW - 1) / BNW;
+    return launch_gemm<EPI_PLAIN>(p, st);
+}
+
+extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
+                                        const void *w1, const void *b1, const void *w2, const void *b2,
+                                        const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
+                                        void *ab, void *h, void *y, void *stream) {
+    if (!ab || !h || !y || !w2) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd_train: null pointer");
+    if (act != MOE_ACT_SWIGLU && act != MOE_ACT_GELU_NEW)
+        return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd_train: unknown act %d", act);
+    if (M <= 0 || I <= 0 || (M % 64) || (I % 64))
+        return fail(MOE_ERR_SHAPE, "moe_expert_ffn_fwd_train: need M%%64==0 and I%%64==0 (M=%d I=%d)", M, I);
+    if (!aligned16(ab)) return fail(MOE_ERR_ALIGN, "moe_expert_ffn_fwd_train: ab must be 16-byte aligned");
+    int rc = gemm_args_ok("moe_expert_ffn_fwd_train", h, I, 0, w2, group_offsets, G, n_experts_local, max_rows, I, M, y, M);
+    if (rc) return rc;
+    const int N1 = act == MOE_ACT_SWIGLU ? 2 * I : I;
+    // fc1 with the plain epilogue: the packed [a | b] rows of W1 give AB = [a | b] columns (bf16, bias added)
+    rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, a, lda, gather, gather_shift, w1, b1, group_offsets, G, n_experts_local, max_rows,
+                              M, N1, ab, N1, stream);
+    if (rc) return rc;
+    if (max_rows == 0) return 0;
+    rc = launch_act_fwd(act, (const bf16_t *)ab, group_offsets + G, max_rows, I, (bf16_t *)h, (hipStream_t)stream);
+    if (rc) return rc;
+    return moe_grouped_gemm_fwd(MOE_EPI_PLAIN, h, I, nullptr, 0, w2, b2, group_offsets, G, n_experts_local, max_rows, I, M,
+                                y, M, stream);
+}
+
+namespace {
+struct BwdWs {
+    int *k_group, *k_expert;
+    bf16_t *wt, *dh, *dab, *ta, *tb;
+    long long ldk;
+    size_t total;
+};
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+BwdWs carve_bwd(void *ws, int act, int G, int El, int max_rows, int M, int I) {
+    const size_t N1 = act == MOE_ACT_SWIGLU ? 2 * (size_t)I : (size_t)I;
+    BwdWs r;
+    r.ldk = (((long long)max_rows + 63) & ~63ll) + 64ll * G;
+    char *base = (char *)ws;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *ptr = base + off;
+        off += pad256(bytes);
+        return ptr;
+    };
+    r.k_group = (int *)take(sizeof(int) * (size_t)G);
+    r.k_expert = (int *)take(sizeof(int) * ((size_t)El + 1));
+    r.wt = (bf16_t *)take(2 * (size_t)El * M * N1);
+    r.dh = (bf16_t *)take(2 * (size_t)max_rows * I);
+    r.dab = (bf16_t *)take(2 * (size_t)max_rows * N1);
+    r.ta = (bf16_t *)take(2 * (N1 > (size_t)M ? N1 : (size_t)M) * (size_t)r.ldk);
+    r.tb = (bf16_t *)take(2 * ((size_t)I > (size_t)M ? (size_t)I : (size_t)M) * (size_t)r.ldk);
+    r.total = off;
+    return r;
+}
+}  // namespace
+
+extern "C" size_t moe_expert_ffn_bwd_workspace_bytes(int act, int G, int n_experts_local, int max_rows, int M, int I) {
+    if (G < 1 || n_experts_local < 1 || max_rows < 0 || M < 1 || I < 1) return 0;
+    return carve_bwd(nullptr, act, G, n_experts_local, max_rows, M, I).total;
+}
+
+extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
+                                  const void *w1, const void *w2, const void *ab, const void *h, const void *dy,
+                                  const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
+                                  void *da_rows, void *dw1, float *db1, void *dw2, float *db2, void *workspace,
+                                  size_t ws_bytes, void *stream) {
+    const char *fn = "moe_expert_ffn_bwd";
+    if (!a || !w1 || !w2 || !ab || !h || !dy || !group_offsets || !da_rows || !dw1 || !dw2 || !workspace)
+        return fail(MOE_ERR_ARG, "%s: null pointer", fn);
+    if (act != MOE_ACT_SWIGLU && act != MOE_ACT_GELU_NEW) return fail(MOE_ERR_ARG, "%s: unknown act %d", fn, act);
+    if (M <= 0 || I <= 0 || (M % 64) || (I % 64) || G < 1 || G > 4096 || n_experts_local < 1 || (G % n_experts_local) ||
+        max_rows < 0 || gather_shift < 0 || gather_shift > 1 || lda < M || (lda & 7))
+        return fail(MOE_ERR_SHAPE, "%s: need M%%64==0, I%%64==0, G a multiple of n_experts_local, lda>=M, lda%%8==0", fn);
+    for (const void *q : {a, w1, w2, ab, h, dy, (const void *)da_rows, (const void *)dw1, (const void *)dw2,
+                          (const void *)workspace, (const void *)db1, (const void *)db2})
+        if (q && !aligned16(q)) return fail(MOE_ERR_ALIGN, "%s: pointers must be 16-byte aligned", fn);
+    const BwdWs ws = carve_bwd(workspace, act, G, n_experts_local, max_rows, M, I);
+    if (ws_bytes < ws.total) return fail(MOE_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, ws_bytes, ws.total);
+    hipStream_t st = (hipStream_t)stream;
+    const int El = n_experts_local;
+    const int N1 = act == MOE_ACT_SWIGLU ? 2 * I : I;
+    const bf16_t *dyp = (const bf16_t *)dy;
+    int rc;
+    if ((rc = launch_k_offsets(group_offsets, G, El, ws.k_group, ws.k_expert, st))) return rc;
+    // ---- fc2: dH = dY @ W2, dW2 = dY^T @ H, db2 = colsum(dY) ----
+    if ((rc = launch_transpose_batched((const bf16_t *)w2, El, M, I, ws.wt, st))) return rc;  // W2^T [El, I, M]
+    if ((rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, dy, M, nullptr, 0, ws.wt, nullptr, group_offsets, G, El, max_rows, M, I,
+                                   ws.dh, I, stream)))
+        return rc;
+    if ((rc = launch_transpose_rows(dyp, M, nullptr, 0, group_offsets, G, ws.k_group, max_rows, M, ws.ta, ws.ldk, st))) return rc;
+    if ((rc = launch_transpose_rows((const bf16_t *)h, I, nullptr, 0, group_offsets, G, ws.k_group, max_rows, I, ws.tb, ws.ldk,
+                                    st)))
+        return rc;
+    if ((rc = launch_wgrad(ws.ta, ws.tb, ws.ldk, ws.k_expert, El, M, I, (bf16_t *)dw2, st))) return rc;
+    if (db2 && (rc = launch_bias_grad(dyp, group_offsets, G, El, max_rows, M, db2, st))) return rc;
+    // ---- activation ----
+    if (max_rows > 0 &&
+        (rc = launch_act_bwd(act, (const bf16_t *)ab, ws.dh, group_offsets + G, max_rows, I, ws.dab, st)))
+        return rc;
+    // ---- fc1: dA = dAB @ W1, dW1 = dAB^T @ A, db1 = colsum(dAB) ----
+    if ((rc = launch_transpose_batched((const bf16_t *)w1, El, N1, M, ws.wt, st))) return rc;  // W1^T [El, M, N1]
+    if ((rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, ws.dab, N1, nullptr, 0, ws.wt, nullptr, group_offsets, G, El, max_rows, N1,
+                                   M, da_rows, M, stream)))
+        return rc;
+    if ((rc = launch_transpose_rows(ws.dab, N1, nullptr, 0, group_offsets, G, ws.k_group, max_rows, N1, ws.ta, ws.ldk, st)))
+        return rc;
+    if ((rc = launch_transpose_rows((const bf16_t *)a, lda, gather, gather_shift, group_offsets, G, ws.k_group, max_rows, M,
+                                    ws.tb, ws.ldk, st)))
+        return rc;
+    if ((rc = launch_wgrad(ws.ta, ws.tb, ws.ldk, ws.k_expert, El, N1, M, (bf16_t *)dw1, st))) return rc;
+    if (db1 && (rc = launch_bias_grad(ws.dab, group_offsets, G, El, max_rows, N1, db1, st))) return rc;
+    return 0;
 }

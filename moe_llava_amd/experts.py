@@ -161,6 +161,27 @@ class Experts(nn.Module):
         self._ptrs = [p.data_ptr() for p in self._params(specs)]
         return specs[0].act, w1, b1, w2, b2
 
+    # ---- autograd plumbing -------------------------------------------------------------------
+    def param_list(self) -> List[nn.Parameter]:
+        """Expert parameters in the fixed order ``split_grads`` answers in."""
+        return self._params(self._specs())
+
+    def split_grads(self, dw1: Tensor, db1: Optional[Tensor], dw2: Tensor, db2: Optional[Tensor]) -> List[Optional[Tensor]]:
+        """Packed gradients -> one tensor per parameter of ``param_list()`` (views for the weights, bf16 casts of the
+        fp32 column sums for the biases); None for parameters that do not require grad."""
+        specs = self._specs()
+        I = specs[0].fc1[0].weight.shape[0]
+        out: List[Optional[Tensor]] = []
+        for i, s in enumerate(specs):
+            for j, lin in enumerate(s.fc1):
+                out.append(dw1[i, j * I:(j + 1) * I] if lin.weight.requires_grad else None)
+                if lin.bias is not None:
+                    out.append(db1[i, j * I:(j + 1) * I].to(lin.bias.dtype) if lin.bias.requires_grad else None)
+            out.append(dw2[i] if s.fc2.weight.requires_grad else None)
+            if s.fc2.bias is not None:
+                out.append(db2[i].to(s.fc2.bias.dtype) if s.fc2.bias.requires_grad else None)
+        return out
+
     # ---- reference-shaped forward -------------------------------------------------------------
     def forward(self, inputs: Tensor) -> Tensor:
         """``inputs`` [ep, E_local, C, M] (upstream layout): expert ``le`` processes ``inputs[:, le]``.

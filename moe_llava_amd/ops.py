@@ -230,3 +230,143 @@ def combine(y: Tensor, r: Routing, S: int, M: int) -> Tensor:
                                  _stream_ptr(y))
     _lib.check(rc, "moe_combine_fwd")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# backward: thin wrappers of the *_bwd entry points, same validation style
+# ---------------------------------------------------------------------------------------------------
+def _ffn_shapes(act, a, w1, w2):
+    M = a.shape[1]
+    n_local, M2, I = w2.shape
+    n1 = 2 * I if act == ACT_SWIGLU else I
+    if M2 != M or tuple(w1.shape) != (n_local, n1, M):
+        raise ValueError(f"weight shapes w1 {tuple(w1.shape)} / w2 {tuple(w2.shape)} do not match M={M}, act={act}")
+    return M, I, n1, n_local
+
+
+def expert_ffn_train(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
+                     w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
+                     group_offsets: Tensor, max_rows: int):
+    """``expert_ffn`` that keeps what the backward needs: returns (y, ab, h)."""
+    _need(a, "a", torch.bfloat16, 2)
+    _need(w1, "w1", torch.bfloat16, 3)
+    _need(w2, "w2", torch.bfloat16, 3)
+    _need(group_offsets, "group_offsets", torch.int32, 1)
+    M, I, n1, n_local = _ffn_shapes(act, a, w1, w2)
+    G = group_offsets.numel() - 1
+    if gather is not None:
+        _need(gather, "gather", torch.int32, 1)
+        if gather.numel() < max_rows:
+            raise ValueError("gather shorter than max_rows")
+    elif a.shape[0] < max_rows:
+        raise ValueError("a has fewer rows than max_rows")
+    dev = a.device
+    rows = max(max_rows, 1)
+    y = torch.empty((rows, M), dtype=torch.bfloat16, device=dev)
+    ab = torch.empty((rows, n1), dtype=torch.bfloat16, device=dev)
+    h = torch.empty((rows, I), dtype=torch.bfloat16, device=dev)
+    if max_rows == 0:
+        return y, ab, h
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.moe_expert_ffn_fwd_train(
+            act, a.data_ptr(), a.stride(0), gather.data_ptr() if gather is not None else None, gather_shift,
+            w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
+            b2.data_ptr() if b2 is not None else None, group_offsets.data_ptr(), G, n_local, max_rows, M, I,
+            ab.data_ptr(), h.data_ptr(), y.data_ptr(), _stream_ptr(a))
+    _lib.check(rc, "moe_expert_ffn_fwd_train")
+    return y, ab, h
+
+
+def expert_ffn_bwd(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int, w1: Tensor, w2: Tensor,
+                   ab: Tensor, h: Tensor, dy: Tensor, group_offsets: Tensor, max_rows: int,
+                   has_b1: bool, has_b2: bool):
+    """Gradients of the grouped expert MLP: (da_rows [max_rows,M] bf16, dw1, db1|None, dw2, db2|None);
+    weight gradients bf16 in the packed layouts, bias gradients fp32."""
+    for t, name in ((a, "a"), (ab, "ab"), (h, "h"), (dy, "dy")):
+        _need(t, name, torch.bfloat16, 2)
+    _need(w1, "w1", torch.bfloat16, 3)
+    _need(w2, "w2", torch.bfloat16, 3)
+    _need(group_offsets, "group_offsets", torch.int32, 1)
+    M, I, n1, n_local = _ffn_shapes(act, a, w1, w2)
+    G = group_offsets.numel() - 1
+    if G % n_local:
+        raise ValueError("number of groups must be a multiple of the local expert count")
+    rows = max(max_rows, 1)
+    if tuple(ab.shape) != (rows, n1) or tuple(h.shape) != (rows, I) or dy.shape[1] != M or dy.shape[0] < max_rows:
+        raise ValueError("saved activations / dy do not match the forward call")
+    dev = a.device
+    da = torch.empty((rows, M), dtype=torch.bfloat16, device=dev)
+    dw1 = torch.empty_like(w1)
+    dw2 = torch.empty_like(w2)
+    db1 = torch.empty((n_local, n1), dtype=torch.float32, device=dev) if has_b1 else None
+    db2 = torch.empty((n_local, M), dtype=torch.float32, device=dev) if has_b2 else None
+    lib = _lib.load()
+    nws = lib.moe_expert_ffn_bwd_workspace_bytes(act, G, n_local, max_rows, M, I)
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.moe_expert_ffn_bwd(
+            act, a.data_ptr(), a.stride(0), gather.data_ptr() if gather is not None else None, gather_shift,
+            w1.data_ptr(), w2.data_ptr(), ab.data_ptr(), h.data_ptr(), dy.data_ptr(), group_offsets.data_ptr(), G,
+            n_local, max_rows, M, I, da.data_ptr(), dw1.data_ptr(), db1.data_ptr() if has_b1 else None,
+            dw2.data_ptr(), db2.data_ptr() if has_b2 else None, ws.data_ptr(), nws, _stream_ptr(a))
+    _lib.check(rc, "moe_expert_ffn_bwd")
+    return da, dw1, db1, dw2, db2
+
+
+def combine_bwd(dout: Tensor, y: Tensor, r: Routing, S: int, M: int):
+    """(dy [rows,M] bf16, dweight [S,k] fp32) -- backward of ``combine``."""
+    _need(dout, "dout", torch.bfloat16, 2)
+    _need(y, "y", torch.bfloat16, 2)
+    if tuple(dout.shape) != (S, M) or y.shape[1] != M:
+        raise ValueError("dout / y shapes do not match")
+    dy = torch.empty_like(y)
+    k = r.expert_idx.shape[1]
+    dweight = torch.empty((S, k), dtype=torch.float32, device=y.device)
+    lib = _lib.load()
+    with torch.cuda.device(y.device):
+        rc = lib.moe_combine_bwd(dout.data_ptr(), y.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(),
+                                 r.weight.data_ptr(), r.expert_offsets.data_ptr(), S, M, k, dy.data_ptr(),
+                                 dweight.data_ptr(), _stream_ptr(y))
+    _lib.check(rc, "moe_combine_bwd")
+    return dy, dweight
+
+
+def gate_bwd(x: Tensor, logits: Tensor, r: Routing, dweight: Tensor, dl_aux: Optional[Tensor]):
+    """(dlogits [S,E] fp32, dwg [E,M] fp32) -- backward of top2gating and of the gate's F.linear w.r.t. wg."""
+    _need(x, "x", torch.bfloat16, 2)
+    _need(logits, "logits", torch.float32, 2)
+    _need(dweight, "dweight", torch.float32, 2)
+    S, M = x.shape
+    E = logits.shape[1]
+    if dl_aux is not None:
+        _need(dl_aux, "dl_aux", torch.float32)
+    dlogits = torch.empty_like(logits)
+    dwg = torch.empty((E, M), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nws = lib.moe_gate_bwd_workspace_bytes(S, M, E)
+    ws = torch.empty((nws,), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.moe_gate_bwd(x.data_ptr(), logits.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(),
+                              dweight.data_ptr(), dl_aux.data_ptr() if dl_aux is not None else None, S, M, E,
+                              dlogits.data_ptr(), dwg.data_ptr(), ws.data_ptr(), nws, _stream_ptr(x))
+    _lib.check(rc, "moe_gate_bwd")
+    return dlogits, dwg
+
+
+def dispatch_bwd(da_rows: Tensor, r: Routing, dlogits: Optional[Tensor], wg_weight: Optional[Tensor],
+                 S: int, M: int) -> Tensor:
+    """dx [S,M] bf16: sum of the token's compact-row gradients + the gate term dlogits @ wg."""
+    _need(da_rows, "da_rows", torch.bfloat16, 2)
+    E = r.exp_counts.numel()
+    dx = torch.empty((S, M), dtype=torch.bfloat16, device=da_rows.device)
+    lib = _lib.load()
+    with torch.cuda.device(da_rows.device):
+        rc = lib.moe_dispatch_bwd(da_rows.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(),
+                                  r.expert_offsets.data_ptr(),
+                                  dlogits.data_ptr() if dlogits is not None else None,
+                                  wg_weight.data_ptr() if wg_weight is not None else None,
+                                  int(wg_weight is not None and wg_weight.dtype == torch.bfloat16), S, M, E,
+                                  r.expert_idx.shape[1], dx.data_ptr(), _stream_ptr(da_rows))
+    _lib.check(rc, "moe_dispatch_bwd")
+    return dx

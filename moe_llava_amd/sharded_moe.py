@@ -6,7 +6,6 @@ expert GEMM; the Python here only orchestrates launches (and, for ``ep_size > 1`
 from __future__ import annotations
 
 import math
-import warnings
 from typing import Optional
 
 import numpy as np
@@ -56,6 +55,7 @@ class TopKGate(nn.Module):
         self.top2_2nd_expert_sampling = top2_2nd_expert_sampling
         #: optional [S,E] fp32 tensor used instead of a fresh Gumbel sample (parity tests inject the oracle's noise)
         self.noise_override: Optional[Tensor] = None
+        self.last_logits: Optional[Tensor] = None
 
     def _set_ep_group(self, ep_group):
         self.ep_group = ep_group
@@ -81,6 +81,7 @@ class TopKGate(nn.Module):
         if self.noisy_gate_policy is not None:
             raise NotImplementedError("noisy_gate_policy is only used by top-1 gating upstream; not implemented")
         lg = self.logits(x)
+        self.last_logits = lg            # kept for the backward pass (and for inspection)
         S, E = lg.shape
         cf = self.capacity_factor if self.training else self.eval_capacity_factor
         cap = capacity_of(S, E, cf * 2, self.min_capacity)
@@ -150,7 +151,6 @@ class MOELayer(nn.Module):
         self.last_ffn_rows: Optional[int] = None
         #: set to an ops.PhaseTimer to record HIP events around gate / fc1 / fc2 / combine (wall_clock_breakdown)
         self.timer: Optional[ops.PhaseTimer] = None
-        self._warned_grad = False
 
     def _set_ep_group(self, ep_group):
         self.ep_group = ep_group
@@ -160,13 +160,22 @@ class MOELayer(nn.Module):
     def forward(self, *inp) -> Tensor:
         x_in = inp[0]
         used_token = inp[1] if len(inp) > 1 else None
-        if torch.is_grad_enabled() and not self._warned_grad and (
-                x_in.requires_grad or any(p.requires_grad for p in self.parameters())):
-            warnings.warn("moe_llava_amd: the HIP MoE block is forward-only in this release; outputs are detached "
-                          "(backward is SURVEY 8f row f1)")
-            self._warned_grad = True
         if x_in.dtype != torch.bfloat16:
             raise TypeError(f"MoE block runs in bf16 (the reference trains and serves with --bf16); got {x_in.dtype}")
+        wg = self.gate.wg.weight
+        if torch.is_grad_enabled():
+            params = self.experts.param_list()
+            if x_in.requires_grad or wg.requires_grad or any(p.requires_grad for p in params):
+                # training: one autograd node for the whole block; l_aux stays differentiable
+                # because the reference adds it to the loss (llava_stablelm_moe.py:461-472)
+                out, self.l_aux = _MoEBlockFn.apply(self, used_token, x_in, wg, *params)
+                return out
+        out, self.l_aux, _ = self._run(x_in, used_token, save=False)
+        return out
+
+    def _run(self, x_in: Tensor, used_token, save: bool):
+        """gate -> routing -> grouped expert FFN (through the all-to-all when ep_size > 1) -> combine.
+        ``save``: keep what the backward needs and return it as the third value."""
         M = x_in.shape[-1]
         x = x_in.detach().reshape(-1, M)
         if not x.is_contiguous():
@@ -178,19 +187,50 @@ class MOELayer(nn.Module):
         r = self.gate(x, used_token)
         if t is not None:
             t.mark("gate_end")
-        self.l_aux, self.exp_counts, self.last_routing = r.l_aux, r.exp_counts, r
+        self.exp_counts, self.last_routing = r.exp_counts, r
         act, w1, b1, w2, b2 = self.experts.packed(x.device)
+        saved = None
         if self.ep_size == 1:
-            y = ops.expert_ffn(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows, timer=t)
+            if save:
+                y, ab, h = ops.expert_ffn_train(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows)
+                saved = dict(a=x, gather=r.perm, shift=1, ab=ab, h=h, offs=r.expert_offsets, rows=r.max_rows)
+            else:
+                y = ops.expert_ffn(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows, timer=t)
         else:
-            y = self._expert_parallel(x, r, act, w1, b1, w2, b2)
+            y, saved = self._expert_parallel(x, r, act, w1, b1, w2, b2, save)
         out = ops.combine(y, r, S, M)
         if t is not None:
             t.mark("combine_end")
-        return out.reshape(x_in.shape)
+        if save:
+            saved.update(x=x, y=y, r=r, logits=self.gate.last_logits, act=act, w1=w1, w2=w2,
+                         has_b1=b1 is not None, has_b2=b2 is not None)
+        return out.reshape(x_in.shape), r.l_aux, saved
+
+    def _backward(self, saved, dout: Tensor, dl_aux: Optional[Tensor]):
+        """Gradients of the block: (dx, dwg fp32, dw1, db1, dw2, db2)."""
+        x, r = saved["x"], saved["r"]
+        S, M = x.shape
+        dy, dweight = ops.combine_bwd(dout, saved["y"], r, S, M)
+        if self.ep_size == 1:
+            da_rows, dw1, db1, dw2, db2 = ops.expert_ffn_bwd(
+                saved["act"], saved["a"], saved["gather"], saved["shift"], saved["w1"], saved["w2"], saved["ab"],
+                saved["h"], dy, saved["offs"], saved["rows"], saved["has_b1"], saved["has_b2"])
+        else:
+            n_send, n_recv = saved["n_send"], saved["n_recv"]
+            dy_recv = torch.empty((max(n_recv, 1), M), dtype=torch.bfloat16, device=x.device)
+            _all_to_all_rows(dy_recv[:n_recv], dy[:n_send], saved["recv_splits"], saved["send_splits"], self.ep_group)
+            da_recv, dw1, db1, dw2, db2 = ops.expert_ffn_bwd(
+                saved["act"], saved["a"], None, 0, saved["w1"], saved["w2"], saved["ab"], saved["h"], dy_recv,
+                saved["offs"], n_recv, saved["has_b1"], saved["has_b2"])
+            da_rows = torch.empty((max(n_send, r.max_rows, 1), M), dtype=torch.bfloat16, device=x.device)
+            _all_to_all_rows(da_rows[:n_send], da_recv[:n_recv], saved["send_splits"], saved["recv_splits"],
+                             self.ep_group)
+        dlogits, dwg = ops.gate_bwd(x, saved["logits"], r, dweight, dl_aux)
+        dx = ops.dispatch_bwd(da_rows, r, dlogits, self.gate.wg.weight.detach(), S, M)
+        return dx, dwg, dw1, db1, dw2, db2
 
     # ------------------------------------------------------------------------------------------
-    def _expert_parallel(self, x: Tensor, r: ops.Routing, act, w1, b1, w2, b2) -> Tensor:
+    def _expert_parallel(self, x: Tensor, r: ops.Routing, act, w1, b1, w2, b2, save: bool = False):
         """Expert-parallel exchange: rank q of the EP group owns experts [q*El, (q+1)*El).
         Only kept rows travel (variable-split all_to_all_single over RCCL), not upstream's capacity-padded
         [E,C,M] block.  One host sync per call fetches the [ep, E] kept-count matrix that sizes the splits."""
@@ -218,7 +258,44 @@ class MOELayer(nn.Module):
         offs_h = torch.zeros(ep * El + 1, dtype=torch.int32)
         offs_h[1:] = torch.cumsum(recv_mat.reshape(-1), 0).to(torch.int32)
         offs = offs_h.to(x.device, non_blocking=True)
-        y_recv = ops.expert_ffn(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv, timer=self.timer)
+        saved = None
+        if save:
+            y_recv, ab, h = ops.expert_ffn_train(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv)
+            saved = dict(a=recv, ab=ab, h=h, offs=offs, n_send=n_send, n_recv=n_recv, send_splits=send_splits,
+                         recv_splits=recv_splits)
+        else:
+            y_recv = ops.expert_ffn(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv, timer=self.timer)
         y = torch.empty((max(n_send, r.max_rows, 1), M), dtype=torch.bfloat16, device=x.device)
         _all_to_all_rows(y[:n_send], y_recv[:n_recv], send_splits, recv_splits, self.ep_group)
-        return y
+        return y, saved
+
+
+class _MoEBlockFn(torch.autograd.Function):
+    """The whole MoE block as one autograd node: forward = the inference launches plus the saved pre-activations,
+    backward = ``MOELayer._backward``.  Inputs after ``used_token``: x, wg.weight, then ``Experts.param_list()``."""
+
+    @staticmethod
+    def forward(ctx, layer: "MOELayer", used_token, x_in: Tensor, wg: Tensor, *params):
+        out, l_aux, saved = layer._run(x_in, used_token, save=True)
+        ctx.layer, ctx.saved, ctx.x_shape = layer, saved, x_in.shape
+        ctx.wg_dtype = wg.dtype
+        return out, l_aux
+
+    @staticmethod
+    def backward(ctx, dout: Tensor, dl_aux: Optional[Tensor]):
+        layer, saved = ctx.layer, ctx.saved
+        ctx.saved = None                        # free the activations as soon as they are used
+        M = ctx.x_shape[-1]
+        if dout is None:
+            dout = torch.zeros(ctx.x_shape, dtype=torch.bfloat16, device=saved["x"].device)
+        dout = dout.reshape(-1, M)
+        if dout.dtype != torch.bfloat16:
+            dout = dout.to(torch.bfloat16)
+        if not dout.is_contiguous():
+            dout = dout.contiguous()
+        if dl_aux is not None:
+            dl_aux = dl_aux.to(torch.float32).contiguous()
+        dx, dwg, dw1, db1, dw2, db2 = layer._backward(saved, dout, dl_aux)
+        pg = layer.experts.split_grads(dw1, db1, dw2, db2)
+        return (None, None, dx.reshape(ctx.x_shape) if ctx.needs_input_grad[2] else None,
+                dwg.to(ctx.wg_dtype) if ctx.needs_input_grad[3] else None, *pg)
