@@ -265,14 +265,28 @@ __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const bf16_t *_
 
 __global__ __launch_bounds__(256) void gate_wgrad_reduce_kernel(const float *__restrict__ partial, int nchunks, long long EM,
                                                                 float *__restrict__ dwg) {
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= EM) return;
+    // 64 float4 columns per block, 4 interleaved chunk slices per column, fixed-order LDS tree: deterministic
+    __shared__ float4 red[4][64];
+    const int col = threadIdx.x & 63, cs = threadIdx.x >> 6;
+    const long long i = ((long long)blockIdx.x * 64 + col) * 4;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < nchunks; ++c) {
-        const float4 v = *reinterpret_cast<const float4 *>(partial + (long long)c * EM + i);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    if (i < EM) {
+#pragma unroll 4
+        for (int c = cs; c < nchunks; c += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(partial + (long long)c * EM + i);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
     }
-    *reinterpret_cast<float4 *>(dwg + i) = a;
+    red[cs][col] = a;
+    __syncthreads();
+    if (cs == 0 && i < EM) {
+        float4 r = red[0][col];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            r.x += red[k][col].x; r.y += red[k][col].y; r.z += red[k][col].z; r.w += red[k][col].w;
+        }
+        *reinterpret_cast<float4 *>(dwg + i) = r;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -601,7 +615,7 @@ extern "C" int moe_gate_bwd(const void *x, const float *logits, const int32_t *e
     rc = check_launch("gate_wgrad_partial_kernel");
     if (rc) return rc;
     const long long EM = (long long)E * M;
-    hipLaunchKernelGGL(gate_wgrad_reduce_kernel, dim3((unsigned)((EM / 4 + 255) / 256)), dim3(256), 0, st, partial, nchunks, EM,
+    hipLaunchKernelGGL(gate_wgrad_reduce_kernel, dim3((unsigned)((EM / 4 + 63) / 64)), dim3(256), 0, st, partial, nchunks, EM,
                        dwg);
     return check_launch("gate_wgrad_reduce_kernel");
 }

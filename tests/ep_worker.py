@@ -71,8 +71,113 @@ def _install_cpu_stand_ins():
             out[on] += wq[on, j, None] * y[pos[on]].float()
         return out.to(torch.bfloat16)
 
+    # ---- backward stand-ins (torch autograd per group), so the reverse exchange can be rehearsed on the CPU ----
+    def _ffn(act, rows, w1e, b1e, w2e, b2e, I):
+        ab = F.linear(rows, w1e, b1e)
+        if act == ops.ACT_SWIGLU:
+            h = F.silu(ab[:, :I]) * ab[:, I:]
+        else:
+            from oracle.expert_mlps import gelu_new
+            h = gelu_new(ab)
+        return ab, h, F.linear(h, w2e, b2e)
+
+    def expert_ffn_train(act, a, gather, shift, w1, b1, w2, b2, group_offsets, max_rows):
+        M = a.shape[1]
+        n_local, _, I = w2.shape
+        rows_n = max(max_rows, 1)
+        y = torch.zeros(rows_n, M, dtype=torch.bfloat16)
+        ab = torch.zeros(rows_n, w1.shape[1], dtype=torch.bfloat16)
+        h = torch.zeros(rows_n, I, dtype=torch.bfloat16)
+        offs = group_offsets.tolist()
+        for g in range(len(offs) - 1):
+            lo, hi = offs[g], offs[g + 1]
+            if hi > lo:
+                e = g % n_local
+                rows = a[(gather[lo:hi] >> shift).long()] if gather is not None else a[lo:hi]
+                ab[lo:hi], h[lo:hi], y[lo:hi] = _ffn(act, rows, w1[e], None if b1 is None else b1[e], w2[e],
+                                                     None if b2 is None else b2[e], I)
+        return y, ab, h
+
+    def expert_ffn_bwd(act, a, gather, shift, w1, w2, ab, h, dy, group_offsets, max_rows, has_b1, has_b2):
+        M = a.shape[1]
+        n_local, _, I = w2.shape
+        da = torch.zeros(max(max_rows, 1), M, dtype=torch.bfloat16)
+        dw1, dw2 = torch.zeros(w1.shape), torch.zeros(w2.shape)
+        db1 = torch.zeros(n_local, w1.shape[1]) if has_b1 else None
+        db2 = torch.zeros(n_local, M) if has_b2 else None
+        offs = group_offsets.tolist()
+        for g in range(len(offs) - 1):
+            lo, hi = offs[g], offs[g + 1]
+            if hi == lo:
+                continue
+            e = g % n_local
+            rows = (a[(gather[lo:hi] >> shift).long()] if gather is not None else a[lo:hi]).clone().requires_grad_(True)
+            W1, W2 = w1[e].clone().requires_grad_(True), w2[e].clone().requires_grad_(True)
+            # biases do not change any gradient except their own (= column sums), the pre-activation is rebuilt from ab
+            B1 = torch.zeros(w1.shape[1], dtype=torch.bfloat16, requires_grad=True)
+            B2 = torch.zeros(M, dtype=torch.bfloat16, requires_grad=True)
+            with torch.enable_grad():
+                resid = (ab[lo:hi].float() - F.linear(rows, W1).float()).to(torch.bfloat16).detach()   # = b1 (+rounding)
+                pre = F.linear(rows, W1) + resid + B1
+                if act == ops.ACT_SWIGLU:
+                    hh = F.silu(pre[:, :I]) * pre[:, I:]
+                else:
+                    from oracle.expert_mlps import gelu_new
+                    hh = gelu_new(pre)
+                yy = F.linear(hh, W2, B2)
+                yy.backward(dy[lo:hi])
+            da[lo:hi] = rows.grad
+            dw1[e] += W1.grad.float()
+            dw2[e] += W2.grad.float()
+            if has_b1:
+                db1[e] += B1.grad.float()
+            if has_b2:
+                db2[e] += B2.grad.float()
+        return da, dw1.to(torch.bfloat16), db1, dw2.to(torch.bfloat16), db2
+
+    def _pos(r):
+        return (r.expert_offsets[r.expert_idx.long()] + r.slot).long()
+
+    def combine_bwd(dout, y, r, S, M):
+        dy = torch.zeros_like(y)
+        k = r.expert_idx.shape[1]
+        dweight = torch.zeros(S, k)
+        wq = r.weight.to(torch.bfloat16).float()
+        pos = _pos(r)
+        for j in range(k):
+            on = r.slot[:, j] >= 0
+            dy[pos[on, j]] = (wq[on, j, None] * dout[on].float()).to(torch.bfloat16)
+            dweight[on, j] = (dout[on].float() * y[pos[on, j]].float()).sum(1)
+        return dy, dweight
+
+    def gate_bwd(x, logits, r, dweight, dl_aux):
+        S, E = logits.shape
+        lg = logits.clone().requires_grad_(True)
+        with torch.enable_grad():
+            gates = torch.softmax(lg, dim=1)
+            g = gates.gather(1, r.expert_idx.long()) * (r.slot >= 0).float()
+            den = torch.clamp(g.sum(1, keepdim=True), min=torch.finfo(torch.float32).eps)
+            w = g / den
+            ce = torch.bincount(r.expert_idx[:, 0].long(), minlength=E).float() / S
+            l_aux = (gates.mean(0) * ce).mean() * E * E
+            tot = (w * dweight).sum() + (0.0 if dl_aux is None else dl_aux) * l_aux
+            tot.backward()
+        return lg.grad, lg.grad.t() @ x.float()
+
+    def dispatch_bwd(da_rows, r, dlogits, wg_weight, S, M):
+        dx = torch.zeros(S, M)
+        pos = _pos(r)
+        for j in range(r.expert_idx.shape[1]):
+            on = r.slot[:, j] >= 0
+            dx[on] += da_rows[pos[on, j]].float()
+        if dlogits is not None:
+            dx += dlogits @ wg_weight.float()
+        return dx.to(torch.bfloat16)
+
     ops.gate_logits, ops.routing_top2, ops.gather_rows = gate_logits, routing_top2, gather_rows
     ops.expert_ffn, ops.combine = expert_ffn, combine
+    ops.expert_ffn_train, ops.expert_ffn_bwd, ops.combine_bwd = expert_ffn_train, expert_ffn_bwd, combine_bwd
+    ops.gate_bwd, ops.dispatch_bwd = gate_bwd, dispatch_bwd
 
 
 def _build(M, I, E, ep, seed, kind):
@@ -131,6 +236,37 @@ def run(rank: int, world: int, port: int, mode: str, kind: str, result_dir: str)
             assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
         else:
             assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-3)
+        # ---- backward through the exchange: dy rows travel the reverse route ----
+        g2 = torch.Generator().manual_seed(300 + rank)
+        R = torch.randn(1, S, M, generator=g2).to(torch.bfloat16).to(dev)
+        grads = []
+        for model in (full, part):
+            model.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_(True)
+            o, la, _ = model(xg)
+            torch.autograd.backward([o, la], [R, torch.tensor(0.25, device=dev)])
+            grads.append((xg.grad, model.deepspeed_moe.gate.wg.weight.grad))
+        if mode == "gpu":
+            torch.cuda.synchronize()
+        (dx_f, dwg_f), (dx_p, dwg_p) = grads
+        if mode == "gpu":
+            assert torch.equal(dx_p, dx_f), float((dx_p.float() - dx_f.float()).abs().max())
+        else:
+            assert torch.allclose(dx_p.float(), dx_f.float(), rtol=2e-2, atol=2e-3)
+        assert torch.allclose(dwg_p.float(), dwg_f.float(), rtol=1e-4, atol=1e-5)
+        # an expert's weight gradient sums over the tokens of BOTH ranks: all-reduce the ep=1 model's gradients
+        fe = full.deepspeed_moe.experts.deepspeed_experts
+        for le, mod in enumerate(part.deepspeed_moe.experts.deepspeed_experts):
+            for q in range(ep):
+                ref_mod = fe[q * el + le]
+                for (n, p_ref) in ref_mod.named_parameters():
+                    tot = p_ref.grad.detach().float().cpu().clone()
+                    dist.all_reduce(tot)
+                    if q == ep_rank:
+                        got = dict(mod.named_parameters())[n].grad.float().cpu()
+                        scale = float(tot.abs().max())
+                        err = float((got - tot).abs().max())
+                        assert err <= 2e-2 * scale + 1e-6, (n, err, scale)
         dist.barrier()
         with open(os.path.join(result_dir, f"ok_{rank}"), "w") as f:
             f.write(f"S={S} dropped={dropped}\n")

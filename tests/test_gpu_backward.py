@@ -81,7 +81,7 @@ def test_training_forward_equals_inference_forward():
         with torch.no_grad():
             o1, l1, _ = mine(xd)
         o2, l2, _ = mine(xd.clone().requires_grad_(True))
-        assert torch.equal(o1, o2.detach()) and float(l1) == float(l2)
+        assert torch.equal(o1, o2.detach()) and float(l1) == float(l2.detach())
 
 
 def test_frozen_experts_and_idle_expert():
