@@ -101,6 +101,10 @@ int moe_routing_top2_fwd(const float *logits, const float *noise, uint64_t noise
  *   b2           [n_experts_local, M] bf16 or NULL
  *   group_offsets [G+1] int32 on the device
  *   max_rows     host upper bound of group_offsets[G] (sizes the grid and the workspace)
+ *   n_gated      SWIGLU only: hidden channels c >= n_gated skip the SiLU, h[c] = 1 * (Wb x)[c] -- the fork's RePaMLP
+ *                experts, torch.where(mask, silu(gate), 1) * up with a prefix mask
+ *                (moellava/model/language_model/llava_stablelm_moe.py:632-638,649-655; llava_qwen_moe.py:715-721).
+ *                Pass I (or -1) for the ordinary SwiGLU experts; ignored for GELU_NEW.
  *   h_ws         workspace [max_rows, I] bf16
  *   y            output    [max_rows, M] bf16: y[p] = expert(row p), rounded to bf16 per Linear as the
  *                reference's nn.Linear modules do
@@ -109,7 +113,7 @@ int moe_routing_top2_fwd(const float *logits, const float *noise, uint64_t noise
 int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                        const void *w1, const void *b1, const void *w2, const void *b2,
                        const int32_t *group_offsets, int G, int n_experts_local, int max_rows,
-                       int M, int I, void *h_ws, void *y, void *stream);
+                       int M, int I, int n_gated, void *h_ws, void *y, void *stream);
 
 /* epilogues of moe_grouped_gemm_fwd */
 #define MOE_EPI_PLAIN    0 /* out = bf16(acc + bias)                                  (fc2 / down_proj / c_proj) */
@@ -121,10 +125,12 @@ int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gathe
  * row p of group g (expert e = g % n_experts_local).  Same per-expert nn.Linear semantics as above
  * (stablelm/modeling_stablelm_epoch.py:167-168, phi/modeling_phi.py:211-215, qwen/modeling_qwen.py:601-606).
  *   w    [n_experts_local, N (or 2N for SWIGLU), K] bf16;  bias [n_experts_local, N (or 2N)] bf16 or NULL
+ *   n_gated: MOE_EPI_SWIGLU only, as in moe_expert_ffn_fwd (-1 or N = every column gated); ignored otherwise
  * K % 64 == 0, N % 4 == 0, lda >= K, ldo >= N.  One launch. */
 int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                          const void *w, const void *bias, const int32_t *group_offsets, int G,
-                         int n_experts_local, int max_rows, int K, int N, void *out, int64_t ldo, void *stream);
+                         int n_experts_local, int max_rows, int K, int N, int n_gated, void *out, int64_t ldo,
+                         void *stream);
 
 /* moe_gather_rows_fwd: dst[p] = src[gather[p] >> gather_shift] for p < *n_rows_dev (device int32),
  * rows of M bf16.  Builds the expert-sorted send buffer of the expert-parallel all-to-all
@@ -152,7 +158,7 @@ int moe_combine_fwd(const void *y, const int32_t *expert_idx, const int32_t *slo
 int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                              const void *w1, const void *b1, const void *w2, const void *b2,
                              const int32_t *group_offsets, int G, int n_experts_local, int max_rows,
-                             int M, int I, void *ab, void *h, void *y, void *stream);
+                             int M, int I, int n_gated, void *ab, void *h, void *y, void *stream);
 
 size_t moe_expert_ffn_bwd_workspace_bytes(int act, int G, int n_experts_local, int max_rows, int M, int I);
 
@@ -168,7 +174,7 @@ size_t moe_expert_ffn_bwd_workspace_bytes(int act, int G, int n_experts_local, i
 int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                        const void *w1, const void *w2, const void *ab, const void *h, const void *dy,
                        const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
-                       void *da_rows, void *dw1, float *db1, void *dw2, float *db2,
+                       int n_gated, void *da_rows, void *dw1, float *db1, void *dw2, float *db2,
                        void *workspace, size_t ws_bytes, void *stream);
 
 /* moe_combine_bwd: backward of moe_combine_fwd.  dy[pos(s,j)] = bf16( float(bf16(w[s,j])) * dout[s] ) for every kept

@@ -27,21 +27,22 @@ _SIGNATURES = [
       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("moe_expert_ffn_fwd", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     ("moe_grouped_gemm_fwd", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-      c_void_p, c_int64, c_void_p]),
+      c_int, c_void_p, c_int64, c_void_p]),
     ("moe_gather_rows_fwd", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("moe_combine_fwd", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     # ---- backward ----
     ("moe_expert_ffn_fwd_train", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     ("moe_expert_ffn_bwd_workspace_bytes", c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     ("moe_expert_ffn_bwd", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+      c_void_p]),
     ("moe_combine_bwd", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     ("moe_gate_bwd_workspace_bytes", c_size_t, [c_int, c_int, c_int]),

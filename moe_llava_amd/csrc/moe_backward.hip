@@ -19,7 +19,7 @@ namespace moe {
 // ------------------------------------------------------------------------------------------------
 template <int ACT>
 __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t *__restrict__ ab, const int *__restrict__ n_rows_dev,
-                                                      int max_rows, int I, bf16_t *__restrict__ h) {
+                                                      int max_rows, int I, int n_gated, bf16_t *__restrict__ h) {
     int n = *n_rows_dev;
     if (n > max_rows) n = max_rows;
     const int chunks = I >> 3;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t *__restrict__
             unpack8(*reinterpret_cast<const uint4 *>(row + I), b);
             unsigned short hb[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) hb[i] = swiglu_bf16(a[i], b[i]);
+            for (int i = 0; i < 8; ++i) hb[i] = swiglu_bf16(a[i], b[i], c * 8 + i < n_gated);
             out.x = hb[0] | ((unsigned)hb[1] << 16);
             out.y = hb[2] | ((unsigned)hb[3] << 16);
             out.z = hb[4] | ((unsigned)hb[5] << 16);
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t *__restrict__
 // (each product rounded to bf16 as the bf16 tensors of the reference's backward are)
 template <int ACT>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t *__restrict__ ab, const bf16_t *__restrict__ dh,
-                                                      const int *__restrict__ n_rows_dev, int max_rows, int I,
+                                                      const int *__restrict__ n_rows_dev, int max_rows, int I, int n_gated,
                                                       bf16_t *__restrict__ dab) {
     int n = *n_rows_dev;
     if (n > max_rows) n = max_rows;
@@ -74,11 +74,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t *__restrict__
             unpack8(*reinterpret_cast<const uint4 *>(row + I), b);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+                const bool gated = c * 8 + i < n_gated;  // RePaMLP: masked channels are 1 * b, no gradient to a
                 const float sig = fast_sigmoid(a[i]);
-                const float sg = rbf(a[i] * sig);
+                const float sg = gated ? rbf(a[i] * sig) : 1.0f;
                 db[i] = g[i] * sg;
                 const float dsg = rbf(g[i] * b[i]);
-                da[i] = dsg * (sig * (1.f + a[i] * (1.f - sig)));
+                da[i] = gated ? dsg * (sig * (1.f + a[i] * (1.f - sig))) : 0.f;
             }
             *reinterpret_cast<uint4 *>(dab + r * N1 + c * 8) = pack8(da);
             *reinterpret_cast<uint4 *>(dab + r * N1 + I + c * 8) = pack8(db);
@@ -504,23 +505,29 @@ int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst
     return check_launch("transpose_rows_kernel(batched)");
 }
 
-int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, bf16_t *h, hipStream_t st) {
+int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, int n_gated, bf16_t *h,
+                   hipStream_t st) {
+    if (n_gated < 0 || n_gated > I) n_gated = I;
     const int grid = ew_grid((long long)max_rows * (I >> 3));
     if (act == MOE_ACT_SWIGLU)
-        hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_SWIGLU>), dim3(grid), dim3(256), 0, st, ab, n_rows_dev, max_rows, I, h);
+        hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_SWIGLU>), dim3(grid), dim3(256), 0, st, ab, n_rows_dev, max_rows, I, n_gated,
+                           h);
     else
-        hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_GELU_NEW>), dim3(grid), dim3(256), 0, st, ab, n_rows_dev, max_rows, I, h);
+        hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_GELU_NEW>), dim3(grid), dim3(256), 0, st, ab, n_rows_dev, max_rows, I, n_gated,
+                           h);
     return check_launch("act_fwd_kernel");
 }
 
-int launch_act_bwd(int act, const bf16_t *ab, const bf16_t *dh, const int *n_rows_dev, int max_rows, int I, bf16_t *dab,
-                   hipStream_t st) {
+int launch_act_bwd(int act, const bf16_t *ab, const bf16_t *dh, const int *n_rows_dev, int max_rows, int I, int n_gated,
+                   bf16_t *dab, hipStream_t st) {
+    if (n_gated < 0 || n_gated > I) n_gated = I;
     const int grid = ew_grid((long long)max_rows * (I >> 3));
     if (act == MOE_ACT_SWIGLU)
-        hipLaunchKernelGGL((act_bwd_kernel<MOE_ACT_SWIGLU>), dim3(grid), dim3(256), 0, st, ab, dh, n_rows_dev, max_rows, I, dab);
+        hipLaunchKernelGGL((act_bwd_kernel<MOE_ACT_SWIGLU>), dim3(grid), dim3(256), 0, st, ab, dh, n_rows_dev, max_rows, I, n_gated,
+                           dab);
     else
         hipLaunchKernelGGL((act_bwd_kernel<MOE_ACT_GELU_NEW>), dim3(grid), dim3(256), 0, st, ab, dh, n_rows_dev, max_rows, I,
-                           dab);
+                           n_gated, dab);
     return check_launch("act_bwd_kernel");
 }
 

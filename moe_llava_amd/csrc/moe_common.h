@@ -67,7 +67,9 @@ __device__ __forceinline__ float fast_tanh(float u) {
 }
 // SwiGLU on bf16 outputs a, b of the two fc1 Linears: silu rounds to bf16, then the product does
 // (stablelm/modeling_stablelm_epoch.py:167-168, qwen/modeling_qwen.py:601-606)
-__device__ __forceinline__ bf16_t swiglu_bf16(float a, float b) { return f2bf(rbf(fast_silu(a)) * b); }
+__device__ __forceinline__ bf16_t swiglu_bf16(float a, float b, bool gated = true) {
+    return f2bf((gated ? rbf(fast_silu(a)) : 1.0f) * b);  // RePaMLP: masked channels multiply by 1
+}
 // HF NewGELUActivation evaluated the way a bf16 tensor goes through it: every elementwise op rounds to bf16
 // (phi/modeling_phi.py:207,213 with hidden_act "gelu_new", phi/configuration_phi.py:128).
 __device__ __forceinline__ float gelu_new_bf16(float x) {
@@ -90,9 +92,10 @@ int launch_transpose_rows(const bf16_t *src, long long lds, const int *gather, i
                           int G, const int *k_group, int max_rows, int C, bf16_t *dst, long long ldk, hipStream_t st);
 // dst[b, c, r] = src[b, r, c]
 int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst, hipStream_t st);
-int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, bf16_t *h, hipStream_t st);
-int launch_act_bwd(int act, const bf16_t *ab, const bf16_t *dh, const int *n_rows_dev, int max_rows, int I, bf16_t *dab,
+int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, int n_gated, bf16_t *h,
                    hipStream_t st);
+int launch_act_bwd(int act, const bf16_t *ab, const bf16_t *dh, const int *n_rows_dev, int max_rows, int I, int n_gated,
+                   bf16_t *dab, hipStream_t st);
 // out[e, n] = sum over the rows of expert e's groups of d[r, n]  (fp32, zeroed here)
 int launch_bias_grad(const bf16_t *d, const int *group_offsets, int G, int n_experts_local, int max_rows, int N, float *out,
                      hipStream_t st);

@@ -57,6 +57,7 @@ struct GemmParams {
     int K;
     int N_out;         // output columns
     int b_row_offset;  // gated: W row of the first 'b' projection row (= I)
+    int n_gated;       // gated: output columns >= n_gated bypass SiLU (RePaMLP mask); = N_out for plain SwiGLU
     int max_row_tiles;
     int col_tiles;
     // weight-gradient mode (k_offsets != nullptr): group g is expert g with rows_per_group output rows; both operands
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 for (int j = 0; j < 4; ++j) {
                     const float a = rbf(acc[nf][mf][j] + ba[j]);      // bf16 output of the 'a' Linear
                     const float b = rbf(acc[nf + 2][mf][j] + bb[j]);  // bf16 output of the 'b' Linear
-                    const float sg = rbf(fast_silu(a));               // F.silu on a bf16 tensor
+                    // F.silu on a bf16 tensor; RePaMLP: torch.where(mask, silu, 1) (llava_stablelm_moe.py:636-638)
+                    const float sg = (c0 + j < p.n_gated) ? rbf(fast_silu(a)) : 1.0f;
                     h[j] = f2bf(sg * b);
                 }
                 uint2 o;
@@ -413,7 +415,7 @@ extern "C" int moe_debug_read_stamps(unsigned long long *host_dst) {
 
 extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                     const void *w, const void *bias, const int32_t *group_offsets, int G,
-                                    int n_experts_local, int max_rows, int K, int N, void *out, int64_t ldo,
+                                    int n_experts_local, int max_rows, int K, int N, int n_gated, void *out, int64_t ldo,
                                     void *stream) {
     if (epilogue != MOE_EPI_PLAIN && epilogue != MOE_EPI_SWIGLU && epilogue != MOE_EPI_GELU_NEW)
         return fail(MOE_ERR_ARG, "moe_grouped_gemm_fwd: unknown epilogue %d", epilogue);
@@ -436,6 +438,7 @@ extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, co
     p.K = K;
     p.N_out = N;
     p.b_row_offset = N;
+    p.n_gated = (n_gated < 0 || n_gated > N) ? N : n_gated;
     p.ldw = K;
     p.k_offsets = nullptr;
     p.rows_per_group = 0;
@@ -457,7 +460,7 @@ extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, co
 extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                   const void *w1, const void *b1, const void *w2, const void *b2,
                                   const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
-                                  void *h_ws, void *y, void *stream) {
+                                  int n_gated, void *h_ws, void *y, void *stream) {
     if (!h_ws || !y || !w2) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: null pointer");
     if (act != MOE_ACT_SWIGLU && act != MOE_ACT_GELU_NEW) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: unknown act %d", act);
     if (M <= 0 || I <= 0 || (M % 64) || (I % 64))
@@ -466,10 +469,10 @@ extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int
     int rc = gemm_args_ok("moe_expert_ffn_fwd", h_ws, I, 0, w2, group_offsets, G, n_experts_local, max_rows, I, M, y, M);
     if (rc) return rc;
     rc = moe_grouped_gemm_fwd(act == MOE_ACT_SWIGLU ? MOE_EPI_SWIGLU : MOE_EPI_GELU_NEW, a, lda, gather, gather_shift, w1, b1,
-                              group_offsets, G, n_experts_local, max_rows, M, I, h_ws, I, stream);
+                              group_offsets, G, n_experts_local, max_rows, M, I, n_gated, h_ws, I, stream);
     if (rc) return rc;
     return moe_grouped_gemm_fwd(MOE_EPI_PLAIN, h_ws, I, nullptr, 0, w2, b2, group_offsets, G, n_experts_local, max_rows, I, M,
-                                y, M, stream);
+                                -1, y, M, stream);
 }
 
 // out[e] ([R, N] bf16) = A_t[:, Ke] @ W_t[:, Ke]^T with Ke = [k_offsets[e], k_offsets[e+1]): the weight gradient of one
@@ -493,6 +496,7 @@ static int launch_wgrad(const bf16_t *a_t, const bf16_t *w_t, long long ldk, con
     p.K = 0;
     p.N_out = N;
     p.b_row_offset = N;
+    p.n_gated = N;
     p.ldw = ldk;
     p.k_offsets = k_offsets;
     p.rows_per_group = R;
@@ -504,7 +508,7 @@ static int launch_wgrad(const bf16_t *a_t, const bf16_t *w_t, long long ldk, con
 extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                         const void *w1, const void *b1, const void *w2, const void *b2,
                                         const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
-                                        void *ab, void *h, void *y, void *stream) {
+                                        int n_gated, void *ab, void *h, void *y, void *stream) {
     if (!ab || !h || !y || !w2) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd_train: null pointer");
     if (act != MOE_ACT_SWIGLU && act != MOE_ACT_GELU_NEW)
         return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd_train: unknown act %d", act);
@@ -516,13 +520,13 @@ extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, con
     const int N1 = act == MOE_ACT_SWIGLU ? 2 * I : I;
     // fc1 with the plain epilogue: the packed [a | b] rows of W1 give AB = [a | b] columns (bf16, bias added)
     rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, a, lda, gather, gather_shift, w1, b1, group_offsets, G, n_experts_local, max_rows,
-                              M, N1, ab, N1, stream);
+                              M, N1, -1, ab, N1, stream);
     if (rc) return rc;
     if (max_rows == 0) return 0;
-    rc = launch_act_fwd(act, (const bf16_t *)ab, group_offsets + G, max_rows, I, (bf16_t *)h, (hipStream_t)stream);
+    rc = launch_act_fwd(act, (const bf16_t *)ab, group_offsets + G, max_rows, I, n_gated, (bf16_t *)h, (hipStream_t)stream);
     if (rc) return rc;
     return moe_grouped_gemm_fwd(MOE_EPI_PLAIN, h, I, nullptr, 0, w2, b2, group_offsets, G, n_experts_local, max_rows, I, M,
-                                y, M, stream);
+                                -1, y, M, stream);
 }
 
 namespace {
@@ -564,7 +568,7 @@ extern "C" size_t moe_expert_ffn_bwd_workspace_bytes(int act, int G, int n_exper
 extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                   const void *w1, const void *w2, const void *ab, const void *h, const void *dy,
                                   const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
-                                  void *da_rows, void *dw1, float *db1, void *dw2, float *db2, void *workspace,
+                                  int n_gated, void *da_rows, void *dw1, float *db1, void *dw2, float *db2, void *workspace,
                                   size_t ws_bytes, void *stream) {
     const char *fn = "moe_expert_ffn_bwd";
     if (!a || !w1 || !w2 || !ab || !h || !dy || !group_offsets || !da_rows || !dw1 || !dw2 || !workspace)
@@ -587,7 +591,7 @@ extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int
     // ---- fc2: dH = dY @ W2, dW2 = dY^T @ H, db2 = colsum(dY) ----
     if ((rc = launch_transpose_batched((const bf16_t *)w2, El, M, I, ws.wt, st))) return rc;  // W2^T [El, I, M]
     if ((rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, dy, M, nullptr, 0, ws.wt, nullptr, group_offsets, G, El, max_rows, M, I,
-                                   ws.dh, I, stream)))
+                                   -1, ws.dh, I, stream)))
         return rc;
     if ((rc = launch_transpose_rows(dyp, M, nullptr, 0, group_offsets, G, ws.k_group, max_rows, M, ws.ta, ws.ldk, st))) return rc;
     if ((rc = launch_transpose_rows((const bf16_t *)h, I, nullptr, 0, group_offsets, G, ws.k_group, max_rows, I, ws.tb, ws.ldk,
@@ -597,12 +601,12 @@ extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int
     if (db2 && (rc = launch_bias_grad(dyp, group_offsets, G, El, max_rows, M, db2, st))) return rc;
     // ---- activation ----
     if (max_rows > 0 &&
-        (rc = launch_act_bwd(act, (const bf16_t *)ab, ws.dh, group_offsets + G, max_rows, I, ws.dab, st)))
+        (rc = launch_act_bwd(act, (const bf16_t *)ab, ws.dh, group_offsets + G, max_rows, I, n_gated, ws.dab, st)))
         return rc;
     // ---- fc1: dA = dAB @ W1, dW1 = dAB^T @ A, db1 = colsum(dAB) ----
     if ((rc = launch_transpose_batched((const bf16_t *)w1, El, N1, M, ws.wt, st))) return rc;  // W1^T [El, M, N1]
     if ((rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, ws.dab, N1, nullptr, 0, ws.wt, nullptr, group_offsets, G, El, max_rows, N1,
-                                   M, da_rows, M, stream)))
+                                   M, -1, da_rows, M, stream)))
         return rc;
     if ((rc = launch_transpose_rows(ws.dab, N1, nullptr, 0, group_offsets, G, ws.k_group, max_rows, N1, ws.ta, ws.ldk, st)))
         return rc;

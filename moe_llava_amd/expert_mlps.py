@@ -8,6 +8,8 @@ and runs the grouped GEMM); it exists so the modules remain ordinary torch modul
 * StableLM ``MLP``:  ``moellava/model/language_model/stablelm/modeling_stablelm_epoch.py:156-168``
 * Phi ``PhiMLP``:    ``moellava/model/language_model/phi/modeling_phi.py:203-215``
 * Qwen ``QWenMLP``:  ``moellava/model/language_model/qwen/modeling_qwen.py:589-606``
+* the fork's ``RePaMLP`` (masked SwiGLU): ``moellava/model/language_model/llava_stablelm_moe.py:613-655``
+  (StableLM names) and ``llava_qwen_moe.py:693-738`` (Qwen names)
 """
 from __future__ import annotations
 
@@ -58,3 +60,52 @@ class QWenMLP(nn.Module):
 
     def forward(self, x):
         return self.c_proj(self.w1(x) * F.silu(self.w2(x)))
+
+
+class RePaMLP(nn.Module):
+    """Masked-SwiGLU expert of the fork: hidden channels ``>= num_gated_channels`` skip the SiLU (their gate is the
+    constant 1), so after training they can be folded into one dense ``hidden x hidden`` matrix (``reparam``), which
+    leaves a narrower ordinary SwiGLU expert.  ``names`` picks the StableLM or the Qwen parameter names."""
+
+    _NAMES = {"stablelm": ("gate_proj", "up_proj", "down_proj"), "qwen": ("w2", "w1", "c_proj")}
+
+    def __init__(self, hidden_size: int, intermediate_size: int, names: str = "stablelm", bias: bool = False):
+        super().__init__()
+        self.hidden_size, self.intermediate_size = hidden_size, intermediate_size
+        self._gate, self._up, self._down = self._NAMES[names]
+        setattr(self, self._gate, nn.Linear(hidden_size, intermediate_size, bias=bias))
+        setattr(self, self._up, nn.Linear(hidden_size, intermediate_size, bias=bias))
+        setattr(self, self._down, nn.Linear(intermediate_size, hidden_size, bias=bias))
+        if names == "stablelm":
+            self.act_fn = nn.SiLU()
+        self.gated_ratio = 1.0
+        self.num_gated_channels = intermediate_size
+        self.register_buffer("mask", torch.ones(intermediate_size, dtype=torch.bool))
+        self.reparamed = False
+
+    def forward(self, x):
+        gate, up, down = getattr(self, self._gate), getattr(self, self._up), getattr(self, self._down)
+        g = F.silu(gate(x))
+        if not self.reparamed:
+            g = torch.where(self.mask, g, torch.ones_like(g))
+        return down(g * up(x))
+
+    def adjust_gated_ratio(self, gated_ratio: float) -> None:
+        self.gated_ratio = gated_ratio
+        self.num_gated_channels = int(self.intermediate_size * gated_ratio)
+        self.mask.fill_(False)
+        self.mask[: self.num_gated_channels] = True
+
+    def reparam(self):
+        """Fold the ungated channels: returns the ``[hidden, hidden]`` weight of the equivalent dense Linear and
+        shrinks the three projections to the gated channels."""
+        if self.reparamed:
+            return None
+        gate, up, down = getattr(self, self._gate), getattr(self, self._up), getattr(self, self._down)
+        n = self.num_gated_channels
+        folded = up.weight[n:].T @ down.weight[:, n:].T
+        gate.weight = nn.Parameter(gate.weight[:n])
+        up.weight = nn.Parameter(up.weight[:n])
+        down.weight = nn.Parameter(down.weight[:, :n])
+        self.reparamed = True
+        return folded.T

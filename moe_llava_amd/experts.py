@@ -26,6 +26,7 @@ class ExpertSpec:
     act: int                      # ops.ACT_*
     fc1: List[nn.Linear]          # SWIGLU: [a (silu'd), b]; GELU_NEW: [fc1]
     fc2: nn.Linear
+    n_gated: int = -1             # SWIGLU: hidden channels >= n_gated skip the SiLU (RePaMLP); -1 = all gated
 
 
 _ADAPTERS: List[Callable[[nn.Module], Optional[ExpertSpec]]] = []
@@ -44,6 +45,17 @@ def _act_name(m) -> str:
     return type(m).__name__.lower() if m is not None else ""
 
 
+def _repa_gated(e: nn.Module) -> int:
+    """RePaMLP (llava_stablelm_moe.py:613-655, llava_qwen_moe.py:693-738): a bool ``mask`` buffer selects the gated
+    channels until ``reparam()`` has shrunk the projections; the reference only ever builds prefix masks
+    (``adjust_gated_ratio``).  Returns the prefix length, or -1 for ordinary experts."""
+    mask = getattr(e, "mask", None)
+    if not isinstance(mask, Tensor) or mask.dtype != torch.bool or getattr(e, "reparamed", False):
+        return -1
+    n = int(getattr(e, "num_gated_channels", mask.numel()))
+    return -1 if n >= mask.numel() else n
+
+
 def _adapt_builtin(e: nn.Module) -> Optional[ExpertSpec]:
     # StableLM / LLaMA / Mistral / MiniCPM form: down_proj(act_fn(gate_proj(x)) * up_proj(x))
     # (stablelm/modeling_stablelm_epoch.py:156-168)
@@ -51,10 +63,10 @@ def _adapt_builtin(e: nn.Module) -> Optional[ExpertSpec]:
         act = getattr(e, "act_fn", None)
         if act is not None and "silu" not in _act_name(act) and "swish" not in _act_name(act):
             raise NotImplementedError(f"gated expert with activation {type(act).__name__}: only SiLU is implemented")
-        return ExpertSpec(ops.ACT_SWIGLU, [e.gate_proj, e.up_proj], e.down_proj)
+        return ExpertSpec(ops.ACT_SWIGLU, [e.gate_proj, e.up_proj], e.down_proj, _repa_gated(e))
     # Qwen form: c_proj(w1(x) * silu(w2(x)))  (qwen/modeling_qwen.py:589-606): the silu'd projection is w2
     if all(_is_linear(getattr(e, n, None)) for n in ("w1", "w2", "c_proj")):
-        return ExpertSpec(ops.ACT_SWIGLU, [e.w2, e.w1], e.c_proj)
+        return ExpertSpec(ops.ACT_SWIGLU, [e.w2, e.w1], e.c_proj, _repa_gated(e))
     # Phi form: fc2(gelu_new(fc1(x)))  (phi/modeling_phi.py:203-215)
     if all(_is_linear(getattr(e, n, None)) for n in ("fc1", "fc2")):
         act = getattr(e, "activation_fn", None)
@@ -88,14 +100,17 @@ class Experts(nn.Module):
                 p.group_name = expert_group_name
         self._packed: Optional[Dict[str, Optional[Tensor]]] = None
         self._ptrs: Optional[List[int]] = None
+        #: SwiGLU channels >= n_gated skip the SiLU (RePaMLP experts); -1 = ordinary experts.  Refreshed per forward.
+        self.n_gated: int = -1
 
     # ---- packed weights ----------------------------------------------------------------------
     def _specs(self) -> List[ExpertSpec]:
         specs = [describe_expert(e) for e in self.deepspeed_experts]
         a0, n0 = specs[0].act, len(specs[0].fc1)
         for s in specs:
-            if s.act != a0 or len(s.fc1) != n0:
+            if s.act != a0 or len(s.fc1) != n0 or s.n_gated != specs[0].n_gated:
                 raise ValueError("all local experts must share one MLP form")
+        self.n_gated = specs[0].n_gated
         return specs
 
     def _params(self, specs) -> List[nn.Parameter]:
@@ -111,7 +126,7 @@ class Experts(nn.Module):
         """Return (act, w1 [E,N1,M], b1|None, w2 [E,M,I], b2|None), (re)packing when a parameter's storage moved."""
         specs = self._specs()
         params = self._params(specs)
-        ptrs = [p.data_ptr() for p in params]
+        ptrs = [(p.data_ptr(), tuple(p.shape)) for p in params]   # reparam() keeps the address and shrinks the shape
         if self._packed is not None and ptrs == self._ptrs and self._packed["w1"].device == device:
             pk = self._packed
             return specs[0].act, pk["w1"], pk["b1"], pk["w2"], pk["b2"]
@@ -129,36 +144,42 @@ class Experts(nn.Module):
                     raise ValueError("fc1 projections of all local experts must have equal shapes")
             if tuple(s.fc2.weight.shape) != (M, I):
                 raise ValueError(f"fc2 weight {tuple(s.fc2.weight.shape)} does not match {(M, I)}")
-        if M % 64 or I % 64:
-            raise ValueError(f"kernel needs hidden size and expert width to be multiples of 64 (M={M}, I={I})")
+        if M % 64:
+            raise ValueError(f"kernel needs the hidden size to be a multiple of 64 (M={M})")
+        # an expert width that is not a multiple of 64 (RePaMLP after reparam(): int(I * ratio)) is padded with zero
+        # rows / columns: silu(0) * 0 = 0 and zero columns of fc2 add nothing, gradients of the padding are zero
+        Ip = (I + 63) // 64 * 64
+        if specs[0].n_gated >= 0 and any(not bool(e.mask[:specs[0].n_gated].all()) or bool(e.mask[specs[0].n_gated:].any())
+                                         for e in self.deepspeed_experts):
+            raise NotImplementedError("RePaMLP mask is not a prefix mask; only prefix masks are implemented")
         has_b1 = specs[0].fc1[0].bias is not None
         has_b2 = specs[0].fc2.bias is not None
         kw = dict(dtype=torch.bfloat16, device=device)
-        w1 = torch.empty((E, nproj * I, M), **kw)
-        w2 = torch.empty((E, M, I), **kw)
-        b1 = torch.empty((E, nproj * I), **kw) if has_b1 else None
-        b2 = torch.empty((E, M), **kw) if has_b2 else None
+        w1 = torch.zeros((E, nproj * Ip, M), **kw)
+        w2 = torch.zeros((E, M, Ip), **kw)
+        b1 = torch.zeros((E, nproj * Ip), **kw) if has_b1 else None
+        b2 = torch.zeros((E, M), **kw) if has_b2 else None
         with torch.no_grad():
             for i, s in enumerate(specs):
                 for j, lin in enumerate(s.fc1):
                     if (lin.bias is not None) != has_b1:
                         raise ValueError("bias must be present on all fc1 projections or none")
-                    v = w1[i, j * I:(j + 1) * I]
+                    v = w1[i, j * Ip:j * Ip + I]
                     v.copy_(lin.weight.data)
                     lin.weight.data = v
                     if has_b1:
-                        bv = b1[i, j * I:(j + 1) * I]
+                        bv = b1[i, j * Ip:j * Ip + I]
                         bv.copy_(lin.bias.data)
                         lin.bias.data = bv
                 if (s.fc2.bias is not None) != has_b2:
                     raise ValueError("bias must be present on all fc2 projections or none")
-                w2[i].copy_(s.fc2.weight.data)
-                s.fc2.weight.data = w2[i]
+                w2[i, :, :I].copy_(s.fc2.weight.data)
+                s.fc2.weight.data = w2[i, :, :I]
                 if has_b2:
                     b2[i].copy_(s.fc2.bias.data)
                     s.fc2.bias.data = b2[i]
         self._packed = {"w1": w1, "b1": b1, "w2": w2, "b2": b2}
-        self._ptrs = [p.data_ptr() for p in self._params(specs)]
+        self._ptrs = [(p.data_ptr(), tuple(p.shape)) for p in self._params(specs)]
         return specs[0].act, w1, b1, w2, b2
 
     # ---- autograd plumbing -------------------------------------------------------------------
@@ -171,13 +192,14 @@ class Experts(nn.Module):
         fp32 column sums for the biases); None for parameters that do not require grad."""
         specs = self._specs()
         I = specs[0].fc1[0].weight.shape[0]
+        Ip = dw2.shape[2]                                  # padded expert width of the packed layout
         out: List[Optional[Tensor]] = []
         for i, s in enumerate(specs):
             for j, lin in enumerate(s.fc1):
-                out.append(dw1[i, j * I:(j + 1) * I] if lin.weight.requires_grad else None)
+                out.append(dw1[i, j * Ip:j * Ip + I] if lin.weight.requires_grad else None)
                 if lin.bias is not None:
-                    out.append(db1[i, j * I:(j + 1) * I].to(lin.bias.dtype) if lin.bias.requires_grad else None)
-            out.append(dw2[i] if s.fc2.weight.requires_grad else None)
+                    out.append(db1[i, j * Ip:j * Ip + I].to(lin.bias.dtype) if lin.bias.requires_grad else None)
+            out.append(dw2[i, :, :I] if s.fc2.weight.requires_grad else None)
             if s.fc2.bias is not None:
                 out.append(db2[i].to(s.fc2.bias.dtype) if s.fc2.bias.requires_grad else None)
         return out
@@ -192,5 +214,5 @@ class Experts(nn.Module):
         flat = inputs.contiguous().reshape(ep * el * C, M)
         act, w1, b1, w2, b2 = self.packed(flat.device)
         offs = torch.arange(0, (ep * el + 1) * C, C, dtype=torch.int32, device=flat.device)
-        y = ops.expert_ffn(act, flat, None, 0, w1, b1, w2, b2, offs, ep * el * C)
+        y = ops.expert_ffn(act, flat, None, 0, w1, b1, w2, b2, offs, ep * el * C, n_gated=self.n_gated)
         return y[: ep * el * C].reshape(ep, el, C, M)

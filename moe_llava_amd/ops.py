@@ -138,7 +138,8 @@ def routing_top2(logits: Tensor, capacity: int, noise: Optional[Tensor] = None,
 
 def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
                w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
-               group_offsets: Tensor, max_rows: int, timer: Optional["PhaseTimer"] = None) -> Tensor:
+               group_offsets: Tensor, max_rows: int, timer: Optional["PhaseTimer"] = None,
+               n_gated: int = -1) -> Tensor:
     """Grouped expert MLP over compact rows; returns y [max_rows, M] bf16 (rows past the device-side
     group_offsets[G] are left unwritten)."""
     _need(a, "a", torch.bfloat16, 2)
@@ -180,19 +181,19 @@ def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
         if timer is None:
             rc = lib.moe_expert_ffn_fwd(act, a.data_ptr(), a.stride(0), gp, gather_shift, w1.data_ptr(), b1p,
                                         w2.data_ptr(), b2p, group_offsets.data_ptr(), G, n_local, max_rows, M, I,
-                                        h.data_ptr(), y.data_ptr(), _stream_ptr(a))
+                                        n_gated, h.data_ptr(), y.data_ptr(), _stream_ptr(a))
             _lib.check(rc, "moe_expert_ffn_fwd")
         else:
             # same two launches through the single-GEMM primitive, with events between them
             epi = EPI_SWIGLU if act == ACT_SWIGLU else EPI_GELU_NEW
             timer.mark("fc1_begin")
             rc = lib.moe_grouped_gemm_fwd(epi, a.data_ptr(), a.stride(0), gp, gather_shift, w1.data_ptr(), b1p,
-                                          group_offsets.data_ptr(), G, n_local, max_rows, M, I, h.data_ptr(), I,
+                                          group_offsets.data_ptr(), G, n_local, max_rows, M, I, n_gated, h.data_ptr(), I,
                                           _stream_ptr(a))
             _lib.check(rc, "moe_grouped_gemm_fwd(fc1)")
             timer.mark("fc1_end")
             rc = lib.moe_grouped_gemm_fwd(EPI_PLAIN, h.data_ptr(), I, None, 0, w2.data_ptr(), b2p,
-                                          group_offsets.data_ptr(), G, n_local, max_rows, I, M, y.data_ptr(), M,
+                                          group_offsets.data_ptr(), G, n_local, max_rows, I, M, -1, y.data_ptr(), M,
                                           _stream_ptr(a))
             _lib.check(rc, "moe_grouped_gemm_fwd(fc2)")
             timer.mark("fc2_end")
@@ -246,7 +247,7 @@ def _ffn_shapes(act, a, w1, w2):
 
 def expert_ffn_train(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
                      w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
-                     group_offsets: Tensor, max_rows: int):
+                     group_offsets: Tensor, max_rows: int, n_gated: int = -1):
     """``expert_ffn`` that keeps what the backward needs: returns (y, ab, h)."""
     _need(a, "a", torch.bfloat16, 2)
     _need(w1, "w1", torch.bfloat16, 3)
@@ -273,14 +274,14 @@ def expert_ffn_train(act: int, a: Tensor, gather: Optional[Tensor], gather_shift
             act, a.data_ptr(), a.stride(0), gather.data_ptr() if gather is not None else None, gather_shift,
             w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
             b2.data_ptr() if b2 is not None else None, group_offsets.data_ptr(), G, n_local, max_rows, M, I,
-            ab.data_ptr(), h.data_ptr(), y.data_ptr(), _stream_ptr(a))
+            n_gated, ab.data_ptr(), h.data_ptr(), y.data_ptr(), _stream_ptr(a))
     _lib.check(rc, "moe_expert_ffn_fwd_train")
     return y, ab, h
 
 
 def expert_ffn_bwd(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int, w1: Tensor, w2: Tensor,
                    ab: Tensor, h: Tensor, dy: Tensor, group_offsets: Tensor, max_rows: int,
-                   has_b1: bool, has_b2: bool):
+                   has_b1: bool, has_b2: bool, n_gated: int = -1):
     """Gradients of the grouped expert MLP: (da_rows [max_rows,M] bf16, dw1, db1|None, dw2, db2|None);
     weight gradients bf16 in the packed layouts, bias gradients fp32."""
     for t, name in ((a, "a"), (ab, "ab"), (h, "h"), (dy, "dy")):
@@ -308,7 +309,7 @@ def expert_ffn_bwd(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: 
         rc = lib.moe_expert_ffn_bwd(
             act, a.data_ptr(), a.stride(0), gather.data_ptr() if gather is not None else None, gather_shift,
             w1.data_ptr(), w2.data_ptr(), ab.data_ptr(), h.data_ptr(), dy.data_ptr(), group_offsets.data_ptr(), G,
-            n_local, max_rows, M, I, da.data_ptr(), dw1.data_ptr(), db1.data_ptr() if has_b1 else None,
+            n_local, max_rows, M, I, n_gated, da.data_ptr(), dw1.data_ptr(), db1.data_ptr() if has_b1 else None,
             dw2.data_ptr(), db2.data_ptr() if has_b2 else None, ws.data_ptr(), nws, _stream_ptr(a))
     _lib.check(rc, "moe_expert_ffn_bwd")
     return da, dw1, db1, dw2, db2

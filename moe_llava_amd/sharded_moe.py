@@ -189,20 +189,21 @@ class MOELayer(nn.Module):
             t.mark("gate_end")
         self.exp_counts, self.last_routing = r.exp_counts, r
         act, w1, b1, w2, b2 = self.experts.packed(x.device)
+        ng = self.experts.n_gated
         saved = None
         if self.ep_size == 1:
             if save:
-                y, ab, h = ops.expert_ffn_train(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows)
+                y, ab, h = ops.expert_ffn_train(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows, ng)
                 saved = dict(a=x, gather=r.perm, shift=1, ab=ab, h=h, offs=r.expert_offsets, rows=r.max_rows)
             else:
-                y = ops.expert_ffn(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows, timer=t)
+                y = ops.expert_ffn(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows, timer=t, n_gated=ng)
         else:
             y, saved = self._expert_parallel(x, r, act, w1, b1, w2, b2, save)
         out = ops.combine(y, r, S, M)
         if t is not None:
             t.mark("combine_end")
         if save:
-            saved.update(x=x, y=y, r=r, logits=self.gate.last_logits, act=act, w1=w1, w2=w2,
+            saved.update(x=x, y=y, r=r, logits=self.gate.last_logits, act=act, w1=w1, w2=w2, ng=ng,
                          has_b1=b1 is not None, has_b2=b2 is not None)
         return out.reshape(x_in.shape), r.l_aux, saved
 
@@ -214,14 +215,14 @@ class MOELayer(nn.Module):
         if self.ep_size == 1:
             da_rows, dw1, db1, dw2, db2 = ops.expert_ffn_bwd(
                 saved["act"], saved["a"], saved["gather"], saved["shift"], saved["w1"], saved["w2"], saved["ab"],
-                saved["h"], dy, saved["offs"], saved["rows"], saved["has_b1"], saved["has_b2"])
+                saved["h"], dy, saved["offs"], saved["rows"], saved["has_b1"], saved["has_b2"], saved["ng"])
         else:
             n_send, n_recv = saved["n_send"], saved["n_recv"]
             dy_recv = torch.empty((max(n_recv, 1), M), dtype=torch.bfloat16, device=x.device)
             _all_to_all_rows(dy_recv[:n_recv], dy[:n_send], saved["recv_splits"], saved["send_splits"], self.ep_group)
             da_recv, dw1, db1, dw2, db2 = ops.expert_ffn_bwd(
                 saved["act"], saved["a"], None, 0, saved["w1"], saved["w2"], saved["ab"], saved["h"], dy_recv,
-                saved["offs"], n_recv, saved["has_b1"], saved["has_b2"])
+                saved["offs"], n_recv, saved["has_b1"], saved["has_b2"], saved["ng"])
             da_rows = torch.empty((max(n_send, r.max_rows, 1), M), dtype=torch.bfloat16, device=x.device)
             _all_to_all_rows(da_rows[:n_send], da_recv[:n_recv], saved["send_splits"], saved["recv_splits"],
                              self.ep_group)
@@ -260,11 +261,12 @@ class MOELayer(nn.Module):
         offs = offs_h.to(x.device, non_blocking=True)
         saved = None
         if save:
-            y_recv, ab, h = ops.expert_ffn_train(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv)
+            y_recv, ab, h = ops.expert_ffn_train(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv, self.experts.n_gated)
             saved = dict(a=recv, ab=ab, h=h, offs=offs, n_send=n_send, n_recv=n_recv, send_splits=send_splits,
                          recv_splits=recv_splits)
         else:
-            y_recv = ops.expert_ffn(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv, timer=self.timer)
+            y_recv = ops.expert_ffn(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv, timer=self.timer,
+                                    n_gated=self.experts.n_gated)
         y = torch.empty((max(n_send, r.max_rows, 1), M), dtype=torch.bfloat16, device=x.device)
         _all_to_all_rows(y[:n_send], y_recv[:n_recv], send_splits, recv_splits, self.ep_group)
         return y, saved

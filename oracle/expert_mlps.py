@@ -68,3 +68,54 @@ class QWenMLPRef(nn.Module):
         a1 = self.w1(x)
         a2 = self.w2(x)
         return self.c_proj(a1 * F.silu(a2))
+
+
+class RePaMLPRef(nn.Module):
+    """The fork's masked-SwiGLU expert, restated from
+    ``moellava/model/language_model/llava_stablelm_moe.py:613-655`` (StableLM parameter names) and
+    ``llava_qwen_moe.py:693-738`` (Qwen names: the SiLU goes on ``w2``, ``w1`` is the plain projection).
+
+    forward (``:632-638``): not reparamed -> ``down(where(mask, silu(gate(x)), 1) * up(x))``; reparamed -> plain SwiGLU
+    over the shrunk projections.  ``adjust_gated_ratio`` (``:649-655``) sets a prefix mask of
+    ``int(intermediate * ratio)`` channels.  ``reparam`` (``:640-647``) returns
+    ``(up.weight[n:].T @ down.weight[:, n:].T).T`` and keeps the first ``n`` channels.  TEST INFRASTRUCTURE ONLY."""
+
+    def __init__(self, hidden_size: int, intermediate_size: int, names: str = "stablelm"):
+        super().__init__()
+        self.hidden_size, self.intermediate_size = hidden_size, intermediate_size
+        self.names = names
+        g, u, d = ("gate_proj", "up_proj", "down_proj") if names == "stablelm" else ("w2", "w1", "c_proj")
+        self._g, self._u, self._d = g, u, d
+        setattr(self, g, nn.Linear(hidden_size, intermediate_size, bias=False))
+        setattr(self, u, nn.Linear(hidden_size, intermediate_size, bias=False))
+        setattr(self, d, nn.Linear(intermediate_size, hidden_size, bias=False))
+        self.gated_ratio = 1.0
+        self.num_gated_channels = int(intermediate_size * self.gated_ratio)
+        self.register_buffer("mask", torch.ones(intermediate_size, dtype=torch.bool))
+        self.adjust_gated_ratio(self.gated_ratio)
+        self.reparamed = False
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        gate, up, down = getattr(self, self._g), getattr(self, self._u), getattr(self, self._d)
+        if self.reparamed:
+            return down(F.silu(gate(x)) * up(x))
+        x_gate = F.silu(gate(x))
+        x_mask = torch.where(self.mask[None, None, :] if x_gate.dim() == 3 else self.mask, x_gate, torch.ones_like(x_gate))
+        return down(x_mask * up(x))
+
+    def reparam(self):
+        if not self.reparamed:
+            gate, up, down = getattr(self, self._g), getattr(self, self._u), getattr(self, self._d)
+            n = self.num_gated_channels
+            w = up.weight[n:].T @ down.weight[:, n:].T
+            gate.weight = nn.Parameter(gate.weight[:n])
+            up.weight = nn.Parameter(up.weight[:n])
+            down.weight = nn.Parameter(down.weight[:, :n])
+            self.reparamed = True
+            return w.T
+
+    def adjust_gated_ratio(self, gated_ratio):
+        self.gated_ratio = gated_ratio
+        self.num_gated_channels = int(self.intermediate_size * self.gated_ratio)
+        self.mask.fill_(False)
+        self.mask[:self.num_gated_channels] = True

@@ -42,7 +42,7 @@ def _install_cpu_stand_ins():
         dst[:n] = src[(gather[:n] >> shift).long()]
         return dst
 
-    def expert_ffn(act, a, gather, shift, w1, b1, w2, b2, group_offsets, max_rows, timer=None):
+    def expert_ffn(act, a, gather, shift, w1, b1, w2, b2, group_offsets, max_rows, timer=None, n_gated=-1):
         M = a.shape[1]
         n_local, _, I = w2.shape
         y = torch.zeros(max(max_rows, 1), M, dtype=torch.bfloat16)
@@ -81,7 +81,7 @@ def _install_cpu_stand_ins():
             h = gelu_new(ab)
         return ab, h, F.linear(h, w2e, b2e)
 
-    def expert_ffn_train(act, a, gather, shift, w1, b1, w2, b2, group_offsets, max_rows):
+    def expert_ffn_train(act, a, gather, shift, w1, b1, w2, b2, group_offsets, max_rows, n_gated=-1):
         M = a.shape[1]
         n_local, _, I = w2.shape
         rows_n = max(max_rows, 1)
@@ -98,7 +98,7 @@ def _install_cpu_stand_ins():
                                                      None if b2 is None else b2[e], I)
         return y, ab, h
 
-    def expert_ffn_bwd(act, a, gather, shift, w1, w2, ab, h, dy, group_offsets, max_rows, has_b1, has_b2):
+    def expert_ffn_bwd(act, a, gather, shift, w1, w2, ab, h, dy, group_offsets, max_rows, has_b1, has_b2, n_gated=-1):
         M = a.shape[1]
         n_local, _, I = w2.shape
         da = torch.zeros(max(max_rows, 1), M, dtype=torch.bfloat16)

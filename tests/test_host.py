@@ -46,8 +46,8 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.moe_gate_logits_fwd(8, 16, 0, 16, 4, 64, 4, None) == -3           # alignment
     assert lib.moe_routing_top2_fwd(16, None, 0, 4, 1, 2, 1, 16, 16, 16, 16, 16, 16, 16, 16, 16, 1 << 20, None) == -2  # E<2
     assert lib.moe_routing_top2_fwd(16, None, 0, 4, 4, 2, 1, 16, 16, 16, 16, 16, 16, 16, 16, 16, 8, None) == -4  # workspace
-    assert lib.moe_expert_ffn_fwd(7, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 64, 16, 16, None) == -1
-    assert lib.moe_expert_ffn_fwd(0, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 100, 16, 16, None) == -2
+    assert lib.moe_expert_ffn_fwd(7, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 64, -1, 16, 16, None) == -1
+    assert lib.moe_expert_ffn_fwd(0, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 100, -1, 16, 16, None) == -2
     assert lib.moe_combine_fwd(16, 16, 16, 16, 16, 4, 64, 3, 16, None) == -2
 
 
@@ -159,3 +159,36 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+def test_repa_expert_adapter_padding_and_reparam_on_cpu():
+    """RePaMLP (llava_stablelm_moe.py:613-655): prefix mask -> n_gated; reparam() shrinks the projections in place of
+    the same storage address, which must still trigger a re-pack; widths that are not multiples of 64 are padded."""
+    from moe_llava_amd.expert_mlps import RePaMLP
+    from moe_llava_amd.experts import Experts, describe_expert
+    from oracle.expert_mlps import RePaMLPRef
+    for names in ("stablelm", "qwen"):
+        m = RePaMLP(64, 200, names).to(torch.bfloat16)
+        assert describe_expert(m).n_gated == -1                       # ratio 1.0 = ordinary SwiGLU
+        m.adjust_gated_ratio(0.5)
+        assert describe_expert(m).n_gated == 100
+        ex = Experts(m, 2, "ep_size_1")
+        act, w1, b1, w2, b2 = ex.packed(torch.device("cpu"))
+        assert w1.shape == (2, 512, 64) and w2.shape == (2, 64, 256) and ex.n_gated == 100
+        assert float(w1[:, 200:256].abs().max()) == 0 and float(w2[:, :, 200:].abs().max()) == 0
+        r = RePaMLPRef(64, 200, names).to(torch.bfloat16)
+        r.adjust_gated_ratio(0.5)
+        r.load_state_dict(ex.deepspeed_experts[0].state_dict())
+        x = torch.randn(3, 5, 64).to(torch.bfloat16)
+        assert torch.equal(ex.deepspeed_experts[0](x), r(x))          # product mirror == oracle restatement
+        f1 = [e.reparam() for e in ex.deepspeed_experts]
+        f2 = r.reparam()
+        assert torch.equal(f1[0], f2) and f1[0].shape == (64, 64)
+        act, w1b, _, w2b, _ = ex.packed(torch.device("cpu"))
+        assert w1b is not w1 and w1b.shape == (2, 256, 64) and w2b.shape == (2, 64, 128) and ex.n_gated == -1
+        assert torch.equal(ex.deepspeed_experts[0](x), r(x))
+    bad = RePaMLP(64, 128).to(torch.bfloat16)
+    bad.adjust_gated_ratio(0.5)
+    bad.mask[100] = True
+    with pytest.raises(NotImplementedError):
+        Experts(bad, 1, "g").packed(torch.device("cpu"))

@@ -49,10 +49,10 @@ st = torch.cuda.current_stream().cuda_stream
 libs = {v: load(v) for v in a.variants}
 
 def fc1(lib):
-    rc = lib.moe_grouped_gemm_fwd(1, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), None, offs.data_ptr(), E, E, R, M, I, h.data_ptr(), I + P, st)
+    rc = lib.moe_grouped_gemm_fwd(1, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), None, offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, st)
     assert rc == 0, lib.moe_last_error()
 def fc2(lib):
-    rc = lib.moe_grouped_gemm_fwd(0, h.data_ptr(), I + P, None, 0, w2.data_ptr(), None, offs.data_ptr(), E, E, R, I, M, y.data_ptr(), M, st)
+    rc = lib.moe_grouped_gemm_fwd(0, h.data_ptr(), I + P, None, 0, w2.data_ptr(), None, offs.data_ptr(), E, E, R, I, M, -1, y.data_ptr(), M, st)
     assert rc == 0, lib.moe_last_error()
 
 shapes = {"fc1": (fc1, 2.0 * R * 2 * I * M), "fc2": (fc2, 2.0 * R * M * I)}
