@@ -85,6 +85,25 @@ int moe_routing_top2_fwd(const float *logits, const float *noise, uint64_t noise
                          int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets,
                          int32_t *perm, float *l_aux, void *workspace, size_t ws_bytes, void *stream);
 
+/* moe_routing_top1_fwd: index form of upstream top1gating (MoE(k=1), reachable through
+ * moellava/train/train.py:87-93 `top_k_experts` in {1,2}).
+ *   noise / noise_seed   noisy_gate_policy 'RSample': the expert is argmax(logits + Gumbel noise) (tensor, or generated
+ *                        in the kernel from the seed); both NULL/0 = argmax of the gates
+ *   used_token [S] int32 or NULL: tokens with 0 are routed nowhere and do not count (upstream `used_token`)
+ *   use_rts              random token selection: an overflowing expert keeps the `capacity` member tokens with the
+ *                        largest uniform sample (rts_uniform [S,E] fp32, or generated from rts_seed), ties to the
+ *                        lower token index; use_rts = 0 keeps the first `capacity` member tokens in token order
+ *   expert_idx, slot, weight: [S,1]; weight = gates[s, expert] for a kept token (NOT renormalised), 0 if dropped
+ *   exp_counts = member tokens per expert; l_aux = sum(mean(gates) * mean(mask1)) * E
+ *   perm [min(S, E*C)]: perm[expert_offsets[e] + slot] = token   (gather_shift 0 for the FFN)
+ * 1 <= E <= 64.  Fixed launch count (the 6 radix-select passes return at once when no expert overflows). */
+size_t moe_routing_top1_workspace_bytes(int S, int E);
+int moe_routing_top1_fwd(const float *logits, const float *noise, uint64_t noise_seed, const int32_t *used_token,
+                         const float *rts_uniform, uint64_t rts_seed, int use_rts, int S, int E, int capacity,
+                         int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
+                         int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
+                         void *workspace, size_t ws_bytes, void *stream);
+
 /* ---- expert FFN ---------------------------------------------------------------------------
  * Replaces einsum("sec,sm->ecm") dispatch + Experts.forward over the expert MLPs (SURVEY 8a rows
  * a6, a8-a11): a grouped, variable-length bf16 GEMM pair on MFMA with the activation fused into
@@ -185,15 +204,16 @@ int moe_combine_bwd(const void *dout, const void *y, const int32_t *expert_idx, 
 
 size_t moe_gate_bwd_workspace_bytes(int S, int M, int E);
 
-/* moe_gate_bwd: backward of moe_routing_top2_fwd + moe_gate_logits_fwd.
- *   dweight [S,2] fp32 (from moe_combine_bwd), dl_aux device pointer to the gradient of l_aux (or NULL = 0)
+/* moe_gate_bwd: backward of moe_routing_top2_fwd / moe_routing_top1_fwd + moe_gate_logits_fwd.
+ *   top_k 2 or 1; used_token as given to moe_routing_top1_fwd (NULL for top-2)
+ *   dweight [S,top_k] fp32 (from moe_combine_bwd), dl_aux device pointer to the gradient of l_aux (or NULL = 0)
  *   dlogits [S,E] fp32 out: through the renormalisation g_j / clamp(g_1+g_2, eps), the post-drop masks, the
  *           l_aux term E * ce[e] / S and the softmax (the argmax / capacity decisions carry no gradient)
  *   dwg     [E,M] fp32 out = dlogits^T @ float(x)   (deterministic two-stage reduction)
  * The gradient w.r.t. x through the gate is added by moe_dispatch_bwd. */
 int moe_gate_bwd(const void *x_bf16, const float *logits, const int32_t *expert_idx, const int32_t *slot,
-                 const float *dweight, const float *dl_aux, int S, int M, int E, float *dlogits, float *dwg,
-                 void *workspace, size_t ws_bytes, void *stream);
+                 const float *dweight, const float *dl_aux, const int32_t *used_token, int S, int M, int E, int top_k,
+                 float *dlogits, float *dwg, void *workspace, size_t ws_bytes, void *stream);
 
 /* moe_dispatch_bwd: dx[s] = bf16( sum_j da_rows[pos(s,j)] + sum_e dlogits[s,e] * wg[e] ), the backward of the dispatch
  * einsum plus the gate's F.linear w.r.t. its input.  dlogits / wg may both be NULL (no gate term).  dx [S,M] bf16. */

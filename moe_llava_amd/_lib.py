@@ -25,6 +25,10 @@ _SIGNATURES = [
     ("moe_routing_top2_fwd", c_int,
      [c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("moe_routing_top1_workspace_bytes", c_size_t, [c_int, c_int]),
+    ("moe_routing_top1_fwd", c_int,
+     [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("moe_expert_ffn_fwd", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
       c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -47,8 +51,8 @@ _SIGNATURES = [
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     ("moe_gate_bwd_workspace_bytes", c_size_t, [c_int, c_int, c_int]),
     ("moe_gate_bwd", c_int,
-     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-      c_size_t, c_void_p]),
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+      c_void_p, c_void_p, c_size_t, c_void_p]),
     ("moe_dispatch_bwd", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
       c_void_p]),

@@ -153,17 +153,19 @@ __global__ __launch_bounds__(256) void combine_bwd_kernel(const bf16_t *__restri
 // ------------------------------------------------------------------------------------------------
 // routing backward (top-2): dweight [S,2], d l_aux -> dlogits [S,E]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void first_choice_hist_kernel(const int *__restrict__ expert_idx, int S, int E, int topk,
+__global__ __launch_bounds__(256) void first_choice_hist_kernel(const int *__restrict__ expert_idx,
+                                                                const int *__restrict__ used_token, int S, int E, int topk,
                                                                 int *__restrict__ n1) {
     __shared__ int h[64];
     if (threadIdx.x < 64) h[threadIdx.x] = 0;
     __syncthreads();
-    for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) atomicAdd(&h[expert_idx[s * topk]], 1);
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256)
+        if (used_token == nullptr || used_token[s] != 0) atomicAdd(&h[expert_idx[s * topk]], 1);
     __syncthreads();
     if (threadIdx.x < E && h[threadIdx.x]) atomicAdd(&n1[threadIdx.x], h[threadIdx.x]);
 }
 
-template <int EMAX>
+template <int EMAX, int TOPK>
 __global__ __launch_bounds__(256) void routing_top2_bwd_kernel(const float *__restrict__ logits,
                                                                const int *__restrict__ expert_idx,
                                                                const int *__restrict__ slot,
@@ -194,26 +196,30 @@ __global__ __launch_bounds__(256) void routing_top2_bwd_kernel(const float *__re
         g[e] *= inv;
         dg[e] = e < E ? la * (float)n1[e] : 0.f;
     }
-    const int i1 = expert_idx[s * 2], i2 = expert_idx[s * 2 + 1];
-    const bool k1 = slot[s * 2] >= 0, k2 = slot[s * 2 + 1] >= 0;
-    float g1 = 0.f, g2 = 0.f;
+    const int i1 = expert_idx[s * TOPK], i2 = TOPK == 2 ? expert_idx[s * TOPK + 1] : -1;
+    const bool k1 = slot[s * TOPK] >= 0, k2 = TOPK == 2 ? slot[s * TOPK + 1] >= 0 : false;
+    float dg1, dg2 = 0.f;
+    if (TOPK == 2) {
+        float g1 = 0.f, g2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < EMAX; ++e) {
-        if (e == i1 && k1) g1 = g[e];
-        if (e == i2 && k2) g2 = g[e];
-    }
-    const float dw1 = dweight[s * 2], dw2 = dweight[s * 2 + 1];
-    const float dsum = g1 + g2;
-    const float eps = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
-    float dg1, dg2;
-    if (dsum >= eps) {  // clamp(min=eps) passes the gradient where it does not clamp
-        const float den = dsum;
-        const float t = (dw1 * g1 + dw2 * g2) / den;
-        dg1 = (dw1 - t) / den;
-        dg2 = (dw2 - t) / den;
+        for (int e = 0; e < EMAX; ++e) {
+            if (e == i1 && k1) g1 = g[e];
+            if (e == i2 && k2) g2 = g[e];
+        }
+        const float dw1 = dweight[s * 2], dw2 = dweight[s * 2 + 1];
+        const float dsum = g1 + g2;
+        const float eps = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+        if (dsum >= eps) {  // clamp(min=eps) passes the gradient where it does not clamp
+            const float den = dsum;
+            const float t = (dw1 * g1 + dw2 * g2) / den;
+            dg1 = (dw1 - t) / den;
+            dg2 = (dw2 - t) / den;
+        } else {
+            dg1 = dw1 / eps;
+            dg2 = dw2 / eps;
+        }
     } else {
-        dg1 = dw1 / eps;
-        dg2 = dw2 / eps;
+        dg1 = dweight[s];  // top-1: the combine weight is the raw gate of a kept token
     }
     float dotp = 0.f;
 #pragma unroll
@@ -580,12 +586,12 @@ extern "C" size_t moe_gate_bwd_workspace_bytes(int S, int M, int E) {
 }
 
 extern "C" int moe_gate_bwd(const void *x, const float *logits, const int32_t *expert_idx, const int32_t *slot,
-                            const float *dweight, const float *dl_aux, int S, int M, int E, float *dlogits, float *dwg,
-                            void *workspace, size_t ws_bytes, void *stream) {
+                            const float *dweight, const float *dl_aux, const int32_t *used_token, int S, int M, int E,
+                            int top_k, float *dlogits, float *dwg, void *workspace, size_t ws_bytes, void *stream) {
     if (!x || !logits || !expert_idx || !slot || !dweight || !dlogits || !dwg || !workspace)
         return fail(MOE_ERR_ARG, "moe_gate_bwd: null pointer");
-    if (S < 1 || M <= 0 || (M & 7) || E < 2 || E > 64)
-        return fail(MOE_ERR_SHAPE, "moe_gate_bwd: need S>=1, M%%8==0, 2<=E<=64 (S=%d M=%d E=%d)", S, M, E);
+    if (S < 1 || M <= 0 || (M & 7) || E < 1 || E > 64 || (top_k != 1 && top_k != 2) || (top_k == 2 && E < 2))
+        return fail(MOE_ERR_SHAPE, "moe_gate_bwd: need S>=1, M%%8==0, top_k<=E<=64, top_k in {1,2} (S=%d M=%d E=%d)", S, M, E);
     if (!aligned16(x) || !aligned16(dwg) || !aligned16(workspace))
         return fail(MOE_ERR_ALIGN, "moe_gate_bwd: x / dwg / workspace not 16-byte aligned");
     const size_t need = moe_gate_bwd_workspace_bytes(S, M, E);
@@ -596,13 +602,19 @@ extern "C" int moe_gate_bwd(const void *x, const float *logits, const int32_t *e
     hipError_t e = hipMemsetAsync(n1, 0, sizeof(int) * 64, st);
     if (e != hipSuccess) return fail((int)e, "moe_gate_bwd memset: %s", hipGetErrorString(e));
     const int hb = (S + 255) / 256 < 1024 ? (S + 255) / 256 : 1024;
-    hipLaunchKernelGGL(first_choice_hist_kernel, dim3(hb), dim3(256), 0, st, expert_idx, S, E, 2, n1);
+    hipLaunchKernelGGL(first_choice_hist_kernel, dim3(hb), dim3(256), 0, st, expert_idx, used_token, S, E, top_k, n1);
     int rc = check_launch("first_choice_hist_kernel");
     if (rc) return rc;
     const dim3 grid((S + 255) / 256);
 #define LAUNCH_RB(EM)                                                                                                  \
-    hipLaunchKernelGGL((routing_top2_bwd_kernel<EM>), grid, dim3(256), 0, st, logits, expert_idx, slot, dweight, dl_aux, n1, \
-                       S, E, dlogits)
+    do {                                                                                                               \
+        if (top_k == 2)                                                                                                \
+            hipLaunchKernelGGL((routing_top2_bwd_kernel<EM, 2>), grid, dim3(256), 0, st, logits, expert_idx, slot, dweight, \
+                               dl_aux, n1, S, E, dlogits);                                                             \
+        else                                                                                                           \
+            hipLaunchKernelGGL((routing_top2_bwd_kernel<EM, 1>), grid, dim3(256), 0, st, logits, expert_idx, slot, dweight, \
+                               dl_aux, n1, S, E, dlogits);                                                             \
+    } while (0)
     if (E <= 4) LAUNCH_RB(4);
     else if (E <= 8) LAUNCH_RB(8);
     else if (E <= 16) LAUNCH_RB(16);

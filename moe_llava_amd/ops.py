@@ -79,6 +79,11 @@ class Routing:
     l_aux: Tensor           # 0-dim fp32
     max_rows: int           # host bound on expert_offsets[E]
     capacity: int
+    used_token: Optional[Tensor] = None   # [S] int32 mask given to top-1 routing (kept for the backward pass)
+
+    @property
+    def top_k(self) -> int:
+        return self.expert_idx.shape[1]
 
 
 def gate_logits(x: Tensor, wg_weight: Tensor) -> Tensor:
@@ -134,6 +139,50 @@ def routing_top2(logits: Tensor, capacity: int, noise: Optional[Tensor] = None,
                                       l_aux.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(logits))
     _lib.check(rc, "moe_routing_top2_fwd")
     return Routing(expert_idx, slot, weight, exp_counts, kept, offs, perm, l_aux, max_rows, int(capacity))
+
+
+def routing_top1(logits: Tensor, capacity: int, used_token: Optional[Tensor] = None, use_rts: bool = True,
+                 rts_uniform: Optional[Tensor] = None, rts_seed: int = 0, noise: Optional[Tensor] = None,
+                 noise_seed: int = 0, drop_tokens: bool = True) -> Routing:
+    """top1gating in index form.  ``rts_uniform`` / ``noise`` inject the random numbers (parity
+    tests); otherwise they are generated in the kernel from the seeds."""
+    _need(logits, "logits", torch.float32, 2)
+    S, E = logits.shape
+    if S < 1:
+        raise ValueError("routing needs at least one token")
+    dev = logits.device
+    for t, name in ((rts_uniform, "rts_uniform"), (noise, "noise")):
+        if t is not None:
+            _need(t, name, torch.float32, 2)
+            if t.shape != logits.shape or t.device != dev:
+                raise ValueError(f"{name} must match logits in shape and device")
+    ut = None
+    if used_token is not None:
+        if used_token.numel() != S or used_token.device != dev:
+            raise ValueError("used_token must have one entry per token, on the logits' device")
+        ut = (used_token.reshape(-1) != 0).to(torch.int32).contiguous()
+    max_rows = min(S, E * int(capacity)) if drop_tokens else S
+    i32 = dict(dtype=torch.int32, device=dev)
+    expert_idx = torch.empty((S, 1), **i32)
+    slot = torch.empty((S, 1), **i32)
+    weight = torch.empty((S, 1), dtype=torch.float32, device=dev)
+    exp_counts = torch.empty((E,), dtype=torch.int64, device=dev)
+    kept = torch.empty((E,), **i32)
+    offs = torch.empty((E + 1,), **i32)
+    perm = torch.empty((max(max_rows, 1),), **i32)
+    l_aux = torch.empty((), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    ws_bytes = lib.moe_routing_top1_workspace_bytes(S, E)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.moe_routing_top1_fwd(
+            logits.data_ptr(), noise.data_ptr() if noise is not None else None, int(noise_seed) & 0xFFFFFFFFFFFFFFFF,
+            ut.data_ptr() if ut is not None else None, rts_uniform.data_ptr() if rts_uniform is not None else None,
+            int(rts_seed) & 0xFFFFFFFFFFFFFFFF, int(bool(use_rts)), S, E, int(capacity), int(bool(drop_tokens)),
+            expert_idx.data_ptr(), slot.data_ptr(), weight.data_ptr(), exp_counts.data_ptr(), kept.data_ptr(),
+            offs.data_ptr(), perm.data_ptr(), l_aux.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(logits))
+    _lib.check(rc, "moe_routing_top1_fwd")
+    return Routing(expert_idx, slot, weight, exp_counts, kept, offs, perm, l_aux, max_rows, int(capacity), ut)
 
 
 def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
@@ -349,7 +398,8 @@ def gate_bwd(x: Tensor, logits: Tensor, r: Routing, dweight: Tensor, dl_aux: Opt
     ws = torch.empty((nws,), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         rc = lib.moe_gate_bwd(x.data_ptr(), logits.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(),
-                              dweight.data_ptr(), dl_aux.data_ptr() if dl_aux is not None else None, S, M, E,
+                              dweight.data_ptr(), dl_aux.data_ptr() if dl_aux is not None else None,
+                              r.used_token.data_ptr() if r.used_token is not None else None, S, M, E, r.top_k,
                               dlogits.data_ptr(), dwg.data_ptr(), ws.data_ptr(), nws, _stream_ptr(x))
     _lib.check(rc, "moe_gate_bwd")
     return dlogits, dwg

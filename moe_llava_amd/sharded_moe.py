@@ -55,6 +55,8 @@ class TopKGate(nn.Module):
         self.top2_2nd_expert_sampling = top2_2nd_expert_sampling
         #: optional [S,E] fp32 tensor used instead of a fresh Gumbel sample (parity tests inject the oracle's noise)
         self.noise_override: Optional[Tensor] = None
+        #: optional [S,E] fp32 uniforms for top-1 random token selection (parity tests inject the oracle's)
+        self.rts_uniform_override: Optional[Tensor] = None
         self.last_logits: Optional[Tensor] = None
 
     def _set_ep_group(self, ep_group):
@@ -74,16 +76,17 @@ class TopKGate(nn.Module):
     def forward(self, x: Tensor, used_token: Optional[Tensor] = None) -> ops.Routing:
         """Returns the index-form routing (upstream returns dense combine/dispatch masks; nothing in the
         reference tree calls the gate directly)."""
-        if self.k != 2:
-            raise NotImplementedError("k=1 (top1gating with RTS) is not implemented in the HIP path yet")
-        if used_token is not None:
-            raise NotImplementedError("used_token is a top-1 feature upstream; not implemented")
-        if self.noisy_gate_policy is not None:
-            raise NotImplementedError("noisy_gate_policy is only used by top-1 gating upstream; not implemented")
+        if self.noisy_gate_policy == "Jitter":
+            raise NotImplementedError("noisy_gate_policy='Jitter' (multiplicative jitter of the gate input) is not "
+                                      "implemented; the reference never sets it")
+        if self.k == 2 and used_token is not None:
+            raise NotImplementedError("used_token is ignored by upstream top2gating; pass it only with k=1")
         lg = self.logits(x)
         self.last_logits = lg            # kept for the backward pass (and for inspection)
         S, E = lg.shape
         cf = self.capacity_factor if self.training else self.eval_capacity_factor
+        if self.k == 1:
+            return self._top1(lg, cf, used_token)
         cap = capacity_of(S, E, cf * 2, self.min_capacity)
         noise, seed = None, 0
         if self.top2_2nd_expert_sampling:
@@ -94,6 +97,28 @@ class TopKGate(nn.Module):
                 # from torch's CPU generator, so torch.manual_seed() makes runs reproducible and no launch is spent
                 seed = int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())
         return ops.routing_top2(lg, cap, noise, self.drop_tokens, noise_seed=seed)
+
+    def _top1(self, lg: Tensor, cf: float, used_token: Optional[Tensor]) -> ops.Routing:
+        """Upstream top1gating: capacity from cf (not doubled), RSample noise on the choice, random
+        token selection among an overflowing expert's tokens, weight = gate of the kept token."""
+        S, E = lg.shape
+        cap = capacity_of(S, E, cf, self.min_capacity)
+        if S < self.min_capacity:
+            raise AssertionError("No. of tokens (batch-size) should be greater than min_capacity. Either set "
+                                 "min_capacity to 0 or increase your batch size.")
+        noise, nseed = None, 0
+        if self.noisy_gate_policy == "RSample":
+            noise = self.noise_override
+            nseed = 0 if noise is not None else _fresh_seed()
+        uni, rseed = None, 0
+        if self.use_rts:
+            uni = self.rts_uniform_override
+            rseed = 0 if uni is not None else _fresh_seed()
+        return ops.routing_top1(lg, cap, used_token, self.use_rts, uni, rseed, noise, nseed, self.drop_tokens)
+
+
+def _fresh_seed() -> int:
+    return int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 def _group_is_gloo(group) -> bool:
@@ -190,13 +215,15 @@ class MOELayer(nn.Module):
         self.exp_counts, self.last_routing = r.exp_counts, r
         act, w1, b1, w2, b2 = self.experts.packed(x.device)
         ng = self.experts.n_gated
+        shift = r.top_k - 1                      # perm holds token * top_k + choice
         saved = None
         if self.ep_size == 1:
             if save:
-                y, ab, h = ops.expert_ffn_train(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows, ng)
-                saved = dict(a=x, gather=r.perm, shift=1, ab=ab, h=h, offs=r.expert_offsets, rows=r.max_rows)
+                y, ab, h = ops.expert_ffn_train(act, x, r.perm, shift, w1, b1, w2, b2, r.expert_offsets, r.max_rows, ng)
+                saved = dict(a=x, gather=r.perm, shift=shift, ab=ab, h=h, offs=r.expert_offsets, rows=r.max_rows)
             else:
-                y = ops.expert_ffn(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows, timer=t, n_gated=ng)
+                y = ops.expert_ffn(act, x, r.perm, shift, w1, b1, w2, b2, r.expert_offsets, r.max_rows, timer=t,
+                                   n_gated=ng)
         else:
             y, saved = self._expert_parallel(x, r, act, w1, b1, w2, b2, save)
         out = ops.combine(y, r, S, M)
@@ -252,7 +279,7 @@ class MOELayer(nn.Module):
         recv_splits = recv_mat.sum(1).tolist()
         n_send, n_recv = int(sum(send_splits)), int(sum(recv_splits))
         self.last_ffn_rows = n_recv
-        send = ops.gather_rows(x, r.perm, 1, r.expert_offsets[E:E + 1], n_send)
+        send = ops.gather_rows(x, r.perm, r.top_k - 1, r.expert_offsets[E:E + 1], n_send)
         recv = torch.empty((max(n_recv, 1), M), dtype=torch.bfloat16, device=x.device)
         _all_to_all_rows(recv[:n_recv], send[:n_send], recv_splits, send_splits, self.ep_group)
         # received rows are ordered (src, local expert): ep*El groups, group g uses expert g % El

@@ -71,27 +71,36 @@ def route_top2(logits: Tensor, capacity: int, noise: Optional[Tensor] = None,
     }
 
 
-def route_top1_rts(logits: Tensor, capacity: int, rts_uniform: Tensor,
-                   used_token: Optional[Tensor] = None) -> Dict[str, Tensor]:
+def route_top1_rts(logits: Tensor, capacity: int, rts_uniform: Optional[Tensor],
+                   used_token: Optional[Tensor] = None, noise: Optional[Tensor] = None,
+                   drop_tokens: bool = True) -> Dict[str, Tensor]:
     """Index form of upstream ``top1gating`` with random token selection: per
     expert keep the ``capacity`` member tokens with the largest uniform score;
     slots are ranks among the KEPT tokens in token order; weight = gate (not
-    renormalised)."""
+    renormalised).  ``rts_uniform=None`` = no RTS: the first ``capacity`` member tokens
+    stay.  Equal uniform scores resolve to the lower token index.  ``noise``: 'RSample'
+    policy, expert = argmax(logits + noise).  ``drop_tokens=False``: nothing is dropped."""
     S, E = logits.shape
     gates = F.softmax(logits, dim=1)
-    i1 = torch.argmax(gates, dim=1)
-    member = torch.ones(S, dtype=torch.bool) if used_token is None else used_token.bool()
+    i1 = torch.argmax(logits + noise if noise is not None else gates, dim=1)
+    member = torch.ones(S, dtype=torch.bool) if used_token is None else used_token.reshape(-1) != 0
     n1 = torch.bincount(i1[member], minlength=E)
     me = torch.mean(gates, dim=0)
     ce = n1.float() / S
     l_aux = torch.sum(me * ce) * E
-    score = rts_uniform.gather(1, i1[:, None])[:, 0]
+    if not drop_tokens:
+        capacity = int(n1.max())
+    if rts_uniform is not None:
+        score = rts_uniform.gather(1, i1[:, None])[:, 0].double()
+    else:
+        score = torch.zeros(S, dtype=torch.float64)
     keep = torch.zeros(S, dtype=torch.bool)
     for e in range(E):
         rows = torch.nonzero(member & (i1 == e))[:, 0]
         if rows.numel() > capacity:
-            top = torch.topk(score[rows], k=capacity)[1]
-            keep[rows[top]] = True
+            # stable descending sort: equal scores keep token order
+            order = torch.sort(-score[rows], stable=True)[1]
+            keep[rows[order[:capacity]]] = True
         else:
             keep[rows] = True
     slot = torch.full((S,), -1, dtype=torch.int64)

@@ -116,15 +116,20 @@ def top1gating_dense(logits: Tensor, capacity_factor: float, min_capacity: int,
                      used_token: Optional[Tensor] = None,
                      drop_tokens: bool = True, use_rts: bool = True,
                      rts_uniform: Optional[Tensor] = None,
+                     noise: Optional[Tensor] = None,
                      ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-    """Upstream ``top1gating`` (SURVEY 8(a) footnote / 8(f) row f4), no noisy-gate
-    policy.  With ``use_rts`` upstream draws U(0,1) noise per (token, expert) and
+    """Upstream ``top1gating`` (SURVEY 8(a) footnote / 8(f) row f4).  ``noise`` is the
+    Gumbel sample of noisy_gate_policy 'RSample' (the expert is then argmax(logits + noise)
+    instead of argmax(gates)); 'Jitter' acts on the gate INPUT and is not restated.
+    Without ``use_rts`` upstream's topk runs over a 0/1 column, so which C member tokens
+    survive is whatever torch.topk does with ties (unspecified); this restatement then
+    keeps the FIRST C member tokens in token order, the rule the kernels implement.  With ``use_rts`` upstream draws U(0,1) noise per (token, expert) and
     keeps, per expert, the ``C`` tokens with the largest ``mask*noise``;
     ``rts_uniform`` injects that noise (required for determinism when use_rts)."""
     S, E = logits.shape
     gates = F.softmax(logits, dim=1)
     C = capacity_of(S, E, capacity_factor, min_capacity)
-    first = torch.argmax(gates, dim=1)
+    first = torch.argmax(logits + noise if noise is not None else gates, dim=1)
     m1 = F.one_hot(first, num_classes=E)
     if used_token is not None:
         m1 = torch.einsum("s,se->se", used_token, m1)
@@ -139,7 +144,8 @@ def top1gating_dense(logits: Tensor, capacity_factor: float, min_capacity: int,
             raise ValueError("oracle needs rts_uniform injected when use_rts=True")
         score = m1 * rts_uniform
     else:
-        score = m1
+        # descending in token order inside (0, 1]: first member tokens win
+        score = m1 * ((S - torch.arange(S, dtype=torch.float64)) / S)[:, None]
     if C > S:
         raise AssertionError("No. of tokens (batch-size) should be greater than min_capacity")
     top_idx = torch.topk(score, k=C, dim=0)[1]
@@ -160,8 +166,9 @@ class TopKGateRef(nn.Module):
     def __init__(self, model_dim: int, num_experts: int, k: int = 1,
                  capacity_factor: float = 1.0, eval_capacity_factor: float = 1.0,
                  min_capacity: int = 8, drop_tokens: bool = True, use_rts: bool = True,
-                 top2_2nd_expert_sampling: bool = True):
+                 top2_2nd_expert_sampling: bool = True, noisy_gate_policy: Optional[str] = None):
         super().__init__()
+        self.noisy_gate_policy = noisy_gate_policy
         if k not in (1, 2):
             raise ValueError("Only top-1 and top-2 gatings are supported.")
         self.wg = nn.Linear(model_dim, num_experts, bias=False)
@@ -189,7 +196,8 @@ class TopKGateRef(nn.Module):
         cf = self.capacity_factor if self.training else self.eval_capacity_factor
         if self.k == 1:
             return top1gating_dense(logits, cf, self.min_capacity, used_token,
-                                    self.drop_tokens, self.use_rts, self.rts_uniform)
+                                    self.drop_tokens, self.use_rts, self.rts_uniform,
+                                    self.noise if self.noisy_gate_policy == "RSample" else None)
         noise = None
         if self.top2_2nd_expert_sampling:
             if self.noise is None:
@@ -284,7 +292,7 @@ class MoERef(nn.Module):
         super().__init__()
         assert num_experts % ep_size == 0, \
             f"Number of experts ({num_experts}) should be divisible by expert parallel size ({ep_size})"
-        assert noisy_gate_policy is None, "oracle covers noisy_gate_policy=None only"
+        assert noisy_gate_policy in (None, "RSample"), "oracle covers noisy_gate_policy None / 'RSample' only"
         self.use_residual = use_residual
         self.ep_size = ep_size
         self.expert_group_name = f"ep_size_{ep_size}"
@@ -292,7 +300,7 @@ class MoERef(nn.Module):
         self.num_local_experts = num_experts // ep_size
         experts = ExpertsRef(expert, self.num_local_experts, self.expert_group_name)
         gate = TopKGateRef(hidden_size, num_experts, k, capacity_factor, eval_capacity_factor,
-                           min_capacity, drop_tokens, use_rts, top2_2nd_expert_sampling)
+                           min_capacity, drop_tokens, use_rts, top2_2nd_expert_sampling, noisy_gate_policy)
         self.deepspeed_moe = MOELayerRef(gate, experts, self.expert_group_name,
                                          ep_size, self.num_local_experts)
         if use_residual:

@@ -175,6 +175,30 @@ def test_top1_rts_dense_equals_index():
         assert mine == dense[s]
 
 
+@pytest.mark.parametrize("use_rts,masked,rsample", [(True, True, False), (False, False, False), (False, True, True),
+                                                    (True, False, True)])
+def test_top1_variants_dense_equals_index(use_rts, masked, rsample):
+    """used_token, the no-RTS rule (first C member tokens) and 'RSample' noise: dense restatement == index form."""
+    S, E = 96, 4
+    torch.manual_seed(11)
+    logits = torch.randn(S, E)
+    logits[:, 2] += 1.5
+    u = torch.rand(S, E) if use_rts else None
+    used = (torch.rand(S) > 0.25).long() if masked else None
+    noise = lit.gumbel_noise((S, E), 5) if rsample else None
+    C = lit.capacity_of(S, E, 0.75, 0)
+    l_aux, combine, dispatch, exp_counts = lit.top1gating_dense(logits, 0.75, 0, used, True, use_rts, u, noise)
+    r = ix.route_top1_rts(logits, C, u, used, noise)
+    assert torch.equal(exp_counts, r["exp_counts"])
+    assert int(r["kept_counts"].sum()) < int(r["exp_counts"].sum())          # something was dropped
+    assert float(l_aux) == pytest.approx(float(r["l_aux"]), abs=1e-6)
+    dense = _dense_to_index(combine)
+    for s in range(S):
+        mine = [(int(r["expert_idx"][s, 0]), int(r["slot"][s, 0]), float(r["weight"][s, 0]))] \
+            if int(r["slot"][s, 0]) >= 0 else []
+        assert mine == dense[s]
+
+
 def test_gelu_new_matches_transformers_if_present():
     try:
         from transformers.activations import ACT2FN
