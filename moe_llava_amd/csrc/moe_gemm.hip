@@ -7,12 +7,14 @@
 // Rows are compact and sorted by group; the group -> tile map is computed per block from the device-side
 // group_offsets, so no host sync is needed and surplus blocks of the worst-case grid exit at once.
 //
-// Tile: 256 (rows) x 256 (W rows) x 64 (K) per 512-thread block, 8 waves as 2 (rows) x 4 (W rows), each wave
-// 128 x 64 with v_mfma_f32_16x16x32_bf16.  Both operand tiles are K-contiguous [256][64] bf16 images filled
-// by global_load_lds_dwordx4 (lane-linear LDS destination; the XOR swizzle that makes the ds_read_b128
-// fragment reads conflict-free is applied to the per-lane SOURCE address and again on the read).
-// The MFMA is issued as D = Wfrag x Xfrag so that a lane owns 4 consecutive output columns of one row
-// (8-byte bf16 stores).  Double-buffered LDS (128 KiB), one barrier per K tile.
+// Tile family: BM (rows) x BNW (W rows) x 64 (K) per 512-thread block, 8 waves as 2 (rows) x 4 (W rows), each wave
+// (BM/2) x (BNW/4) with v_mfma_f32_16x16x32_bf16.  BM 256 x BNW 256 is the MFMA-bound tile (prefill / training
+// batches); BM 128/64/32 and BNW 64 exist for the weight-streaming regime (few rows per expert: config 1, decode),
+// where what matters is how many weight bytes are in flight per CU and how many blocks the grid has.
+// Both operand tiles are K-contiguous [rows][64] bf16 images filled by global_load_lds_dwordx4 (lane-linear LDS
+// destination; the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied to the per-lane
+// SOURCE address and again on the read).  The MFMA is issued as D = Wfrag x Xfrag so that a lane owns 4 consecutive
+// output columns of one row.  Ring of NS LDS slots, one counted vmcnt + barrier per K slice.
 //
 // Roofline: MFMA-bound (2*rows*N*K flop per GEMM) when rows per expert >~ 2k; weight-streaming (HBM) bound
 // below that.  Algorithmic bytes per call: weights once + A rows + H write/read + Y write.
@@ -23,12 +25,7 @@ namespace moe {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-constexpr int BM = 256;   // rows per tile
-constexpr int BNW = 256;  // W rows per tile (gated: 128 output columns, plain: 256)
-#ifndef GEMM_BK
-#define GEMM_BK 64
-#endif
-constexpr int BK = GEMM_BK;  // K slice per ring slot: 64 (2 slots, one barrier per 64 of K) or 32 (4 slots)
+constexpr int BK = 64;  // K slice per ring slot
 constexpr int NTHREADS = 512;
 #ifndef GEMM_RS
 #define GEMM_RS 4
@@ -75,15 +72,27 @@ __device__ __forceinline__ void glds16(const bf16_t *gsrc, bf16_t *lds_wave_base
         16, 0, GEMM_AUX);
 }
 
-// LDS: a ring of NS slots, each one K slice of BK: X tile [256][BK] bf16 + W tile [256][BK] bf16.
-// After the K loop the same memory holds the bf16 output tile [256][NC] (+16 B row pad) for full-line stores.
-#ifndef GEMM_NS
-#define GEMM_NS (GEMM_BK == 64 ? 2 : 4)
-#endif
-constexpr int NS = GEMM_NS;  // 3..5 ring slots; NS-1 K slices in flight behind the one being consumed
-constexpr int STAGE_BYTES = 2 * BM * BK * 2;                  // 64 KiB (BK 64) or 32 KiB (BK 32)
-constexpr int EPI_PAD = 16;                                   // bytes of row padding in the output image
-constexpr int LDS_BYTES = (NS * STAGE_BYTES > BM * (BNW * 2 + EPI_PAD)) ? NS * STAGE_BYTES : BM * (BNW * 2 + EPI_PAD);
+constexpr int EPI_PAD = 16;  // bytes of row padding in the output image
+
+// Per-tile constants.  LDS: a ring of NS slots, each one K slice: X tile [BM][64] + W tile [BNW][64] bf16; after the K
+// loop the same memory holds the bf16 output tile [BM][NC] (+16 B row pad) for full-line stores.
+template <int EPI, int BM, int BNW>
+struct Tile {
+    static_assert(BM == 256 || BM == 128 || BM == 64 || BM == 32, "row tile");
+    static_assert(BNW == 256 || BNW == 128 || (BNW == 64 && EPI != EPI_SWIGLU), "column tile");
+    static constexpr int SLOT_ELEMS = (BM + BNW) * BK;
+    static constexpr int SLOT_BYTES = SLOT_ELEMS * 2;
+    // big tile: 2 x 64 KiB (one barrier per 64 of K measured best); small tiles stream weights with a long serial K
+    // loop per block, so the ring is as deep as ~144 KiB allow (at most 8 slots): the time per K slice is the
+    // fill latency divided by the slices in flight
+    static constexpr int NS = (BM == 256 && BNW == 256) ? 2 : (147456 / SLOT_BYTES >= 8 ? 8 : 147456 / SLOT_BYTES);
+    static constexpr int NC = (EPI == EPI_SWIGLU) ? BNW / 2 : BNW;  // output columns per tile
+    static constexpr int ROWB = NC * 2 + EPI_PAD;                   // bytes per image row
+    static constexpr int LDS_BYTES = NS * SLOT_BYTES > BM * ROWB ? NS * SLOT_BYTES : BM * ROWB;
+    static constexpr int MF = BM / 32;   // 16-row fragments per wave (wave tile BM/2 rows)
+    static constexpr int NF = BNW / 64;  // 16-W-row fragments per wave (wave tile BNW/4 W rows)
+    static constexpr int WNT = BNW / 4;  // W rows per wave
+};
 
 #ifdef GEMM_STAMPS
 // Diagnostic build only (cdna guide section 7, in-kernel stamps): per-wave cycle sums of the K-loop segments go to a
@@ -105,9 +114,11 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int EPI>
+template <int EPI, int BM, int BNW>
 __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    using T = Tile<EPI, BM, BNW>;
+    constexpr int NS = T::NS, MF = T::MF, NF = T::NF, WNT = T::WNT, NC = T::NC, ROWB = T::ROWB;
+    __shared__ __attribute__((aligned(16))) char lds[T::LDS_BYTES];
 
     // ---- block -> (row tile, col tile): XCD-contiguous chunks, then super-rows of RS row tiles ----
     const int nwg = gridDim.x;
@@ -160,12 +171,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
 
-    // ---- staging sources.  One LDS-DMA piece = one wave instruction = 1 KiB = PR rows x (BK*2) bytes, lane-linear
-    //      in LDS; the wave handles NP consecutive pieces of both tiles.  LDS slot c (16 B) of a row holds source chunk
-    //      c ^ xsw(row), which makes every 16-lane ds_read_b128 group of the fragment reads hit 16 distinct 16-B bank
-    //      slots (xsw is applied on the per-lane SOURCE address and again on the read; the LDS image stays linear). ----
-    constexpr int CH = BK / 8;           // 16-byte chunks per row (4 or 8)
-    constexpr int PR = 64 / CH;          // rows per piece (16 or 8)
+    // ---- staging sources.  One LDS-DMA piece = one wave instruction = 1 KiB = 8 rows x 128 bytes, lane-linear in
+    //      LDS.  LDS slot c (16 B) of a row holds source chunk c ^ xsw(row), which makes every 16-lane ds_read_b128
+    //      group of the fragment reads hit 16 distinct 16-B bank slots (xsw is applied on the per-lane SOURCE address
+    //      and again on the read; the LDS image stays linear). ----
+    constexpr int CH = BK / 8;  // 16-byte chunks per row (8)
+    constexpr int PR = 64 / CH; // rows per piece (8)
 #ifndef GEMM_LOADER_WAVES
 #define GEMM_LOADER_WAVES 4
 #endif
@@ -173,26 +184,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     // slice's 64 pieces from all 8 waves cost each wave 640-1500 cycles at the head of every step with its SIMD's
     // matrix pipe idle.  With LW = 4 (one loader per SIMD) the partner wave starts its MFMAs at once: +2..4 %.
     constexpr int LW = GEMM_LOADER_WAVES;
-    constexpr int NP = BM / PR / LW;        // pieces per loader wave per tile
+    constexpr int NPX = BM / PR / LW;   // X pieces per loader wave and slice (>= 1: BM >= 32)
+    constexpr int NPW = BNW / PR / LW;  // W pieces per loader wave and slice
+    static_assert(NPX >= 1 && NPW >= 1, "tile too small for the loader split");
+    constexpr int PP = NPX + NPW;       // LDS-DMA instructions per loader wave and slice
     const bool loader = __builtin_amdgcn_readfirstlane(wave) < LW;
     const int lwave = wave % LW;
-    auto xsw = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((4 - ((row >> 2) & 3)) & 3); };
-    const bf16_t *a_src[NP];
-    const bf16_t *w_src[NP];
+    auto xsw = [](int row) { return (row >> 1) & 7; };
+    const bf16_t *a_src[NPX];
+    const bf16_t *w_src[NPW];
     {
         const int rr = lane / CH, c = lane % CH;
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int row = (lwave * NP + j) * PR + rr;  // 0..255
+        for (int j = 0; j < NPX; ++j) {
+            const int row = (lwave * NPX + j) * PR + rr;  // 0..BM-1
             const int cs = c ^ xsw(row);
             int prow = row_begin + row;
             if (prow > row_end - 1) prow = row_end - 1;  // clamp: rows past the group end are never stored
             const long long srow = p.gather ? (long long)(p.gather[prow] >> p.gather_shift) : (long long)(prow - a_row0);
             a_src[j] = abase + srow * p.lda + cs * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int row = (lwave * NPW + j) * PR + rr;  // 0..BNW-1
+            const int cs = c ^ xsw(row);
             int wrow;
             if (EPI == EPI_SWIGLU) {
-                const int col = ct * (BNW / 2) + (row >> 6) * 32 + (row & 31);
-                wrow = min(col, p.N_out - 1) + ((row >> 5) & 1) * p.b_row_offset;
+                // wave wn' owns LDS W rows [wn'*WNT, +WNT): first half 'a' rows, second half 'b' rows of its columns
+                const int wq = row / WNT, within = row % WNT;
+                const int col = ct * NC + wq * (WNT / 2) + (within % (WNT / 2));
+                wrow = min(col, p.N_out - 1) + (within / (WNT / 2)) * p.b_row_offset;
             } else {
                 wrow = min(ct * BNW + row, p.N_out - 1);
             }
@@ -200,14 +221,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         }
     }
     bf16_t *const lds_e = reinterpret_cast<bf16_t *>(lds);
+    const int nk = p.k_offsets ? (p.k_offsets[grp + 1] - k_first) / BK : p.K / BK;  // K % 64 == 0; wgrad: may be 0
     auto stage = [&](int buf, int kt) {
         if (!loader) return;
-        bf16_t *xa = lds_e + buf * (STAGE_BYTES / 2) + lwave * NP * 512;
+        bf16_t *slot = lds_e + buf * T::SLOT_ELEMS;
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            glds16(a_src[j] + kt * BK, xa + j * 512);
-            glds16(w_src[j] + kt * BK, xa + BM * BK + j * 512);
-        }
+        for (int j = 0; j < NPX; ++j) glds16(a_src[j] + kt * BK, slot + (lwave * NPX + j) * 512);
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) glds16(w_src[j] + kt * BK, slot + BM * BK + (lwave * NPW + j) * 512);
     };
 
     // ---- fragment read offsets (elements): lane (fr, fq) reads row 16*t + fr, k chunk ks*4 + fq ----
@@ -216,19 +237,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     int koff[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) koff[ks] = ((ks * 4 + fq) ^ xsw(fr)) * 8;
-    const int x_off = (wm * 128 + fr) * BK;
-    const int w_off = BM * BK + (wn * 64 + fr) * BK;
+    const int x_off = (wm * (BM / 2) + fr) * BK;
+    const int w_off = BM * BK + (wn * WNT + fr) * BK;
 
-    f32x4_t acc[4][8];
+    f32x4_t acc[NF][MF];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
+    for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-        for (int mf = 0; mf < 8; ++mf) acc[nf][mf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.k_offsets ? (p.k_offsets[grp + 1] - k_first) / BK : p.K / BK;  // K % 64 == 0; wgrad: may be 0
     // K loop: ring of NS slots, NS-1 K slices of LDS-DMA in flight behind the one being consumed, one counted
-    // vmcnt + raw s_barrier per slice.  At step kt the slices issued behind kt are min(NS-2, nk-1-kt), 2*NP LDS-DMA
-    // pieces per wave each.  (Measured: one barrier per 64 of K with 2 slots beats 32 of K with 4 or 5 slots.)
+    // vmcnt + raw s_barrier per slice.  At step kt the slices issued behind kt are min(NS-2, nk-1-kt), PP LDS-DMA
+    // instructions per loader wave each.
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) stage(s, s);
@@ -237,11 +257,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #endif
     for (int kt = 0; kt < nk; ++kt) {
         const int ahead = nk - 1 - kt;
+        static_assert((NS - 2) * PP < 64, "vmcnt field");
         switch (ahead < NS - 2 ? ahead : NS - 2) {
             case 0: wait_vm_barrier<0>(); break;
-            case 1: wait_vm_barrier<2 * NP>(); break;
-            case 2: wait_vm_barrier<4 * NP>(); break;
-            default: wait_vm_barrier<6 * NP>(); break;
+            case 1: wait_vm_barrier<PP>(); break;
+            case 2: wait_vm_barrier<(NS > 3 ? 2 : 0) * PP>(); break;
+            case 3: wait_vm_barrier<(NS > 4 ? 3 : 0) * PP>(); break;
+            case 4: wait_vm_barrier<(NS > 5 ? 4 : 0) * PP>(); break;
+            case 5: wait_vm_barrier<(NS > 6 ? 5 : 0) * PP>(); break;
+            default: wait_vm_barrier<(NS > 7 ? 6 : 0) * PP>(); break;
         }
 #ifdef GEMM_STAMPS
         const unsigned long long st_t1 = stamp();
@@ -253,23 +277,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         const unsigned long long st_t2 = stamp();
 #endif
 #ifndef GEMM_ABLATE_NO_MFMA
-        const bf16_t *lb = lds_e + (kt % NS) * (STAGE_BYTES / 2);
+        const bf16_t *lb = lds_e + (kt % NS) * T::SLOT_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8_t xf[8], wf[4];
+            bf16x8_t xf[MF], wf[NF];
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < NF; ++nf)
                 wf[nf] = *reinterpret_cast<const bf16x8_t *>(lb + w_off + nf * 16 * BK + koff[ks]);
 #pragma unroll
-            for (int mf = 0; mf < 8; ++mf)
+            for (int mf = 0; mf < MF; ++mf)
                 xf[mf] = *reinterpret_cast<const bf16x8_t *>(lb + x_off + mf * 16 * BK + koff[ks]);
 #ifndef GEMM_NO_SETPRIO
             __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster together (+1..3 % measured)
 #endif
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
+            for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
-                for (int mf = 0; mf < 8; ++mf)
+                for (int mf = 0; mf < MF; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
             }
 #ifndef GEMM_NO_SETPRIO
@@ -287,21 +311,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #endif
 #ifdef GEMM_ABLATE_NO_STORE
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
+    for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-        for (int mf = 0; mf < 8; ++mf) asm volatile("" ::"v"(acc[nf][mf]));
+        for (int mf = 0; mf < MF; ++mf) asm volatile("" ::"v"(acc[nf][mf]));
     return;
 #endif
 
     // ---- epilogue: activation in registers -> bf16 tile image in LDS -> 16-byte, full-line global stores ----
-    constexpr int NC = (EPI == EPI_SWIGLU) ? BNW / 2 : BNW;  // output columns per tile
-    constexpr int ROWB = NC * 2 + EPI_PAD;                   // bytes per image row
     const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
     __syncthreads();  // every wave is done reading the ring
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
-            const int cl = wn * 32 + nf * 16 + fq * 4;  // column inside the tile
+        for (int nf = 0; nf < NF / 2; ++nf) {
+            const int cl = wn * (WNT / 2) + nf * 16 + fq * 4;  // column inside the tile
             const int c0 = ct * NC + cl;
             float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
             if (bias && c0 < p.N_out) {
@@ -312,12 +334,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 }
             }
 #pragma unroll
-            for (int mf = 0; mf < 8; ++mf) {
+            for (int mf = 0; mf < MF; ++mf) {
                 unsigned short h[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float a = rbf(acc[nf][mf][j] + ba[j]);      // bf16 output of the 'a' Linear
-                    const float b = rbf(acc[nf + 2][mf][j] + bb[j]);  // bf16 output of the 'b' Linear
+                    const float a = rbf(acc[nf][mf][j] + ba[j]);            // bf16 output of the 'a' Linear
+                    const float b = rbf(acc[nf + NF / 2][mf][j] + bb[j]);   // bf16 output of the 'b' Linear
                     // F.silu on a bf16 tensor; RePaMLP: torch.where(mask, silu, 1) (llava_stablelm_moe.py:636-638)
                     const float sg = (c0 + j < p.n_gated) ? rbf(fast_silu(a)) : 1.0f;
                     h[j] = f2bf(sg * b);
@@ -325,13 +347,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 uint2 o;
                 o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
                 o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-                *reinterpret_cast<uint2 *>(lds + (wm * 128 + mf * 16 + fr) * ROWB + cl * 2) = o;
+                *reinterpret_cast<uint2 *>(lds + (wm * (BM / 2) + mf * 16 + fr) * ROWB + cl * 2) = o;
             }
         }
     } else {
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int cl = wn * 64 + nf * 16 + fq * 4;
+        for (int nf = 0; nf < NF; ++nf) {
+            const int cl = wn * WNT + nf * 16 + fq * 4;
             const int c0 = ct * NC + cl;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
             if (bias && c0 < p.N_out) {
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 for (int j = 0; j < 4; ++j) bv[j] = bf2f(bias[c0 + j]);
             }
 #pragma unroll
-            for (int mf = 0; mf < 8; ++mf) {
+            for (int mf = 0; mf < MF; ++mf) {
                 unsigned short h[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 uint2 o;
                 o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
                 o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-                *reinterpret_cast<uint2 *>(lds + (wm * 128 + mf * 16 + fr) * ROWB + cl * 2) = o;
+                *reinterpret_cast<uint2 *>(lds + (wm * (BM / 2) + mf * 16 + fr) * ROWB + cl * 2) = o;
             }
         }
     }
@@ -383,12 +405,75 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #endif
 }
 
-template <int EPI>
-static int launch_gemm(const GemmParams &p, hipStream_t st) {
-    const int grid = p.max_row_tiles * p.col_tiles;
+// Tile choice.  rows_hint = host upper bound of the mean rows per group.  The 256-row tile is the MFMA-bound one; below
+// that the job is weight streaming: smaller row tiles waste fewer X rows and leave LDS for more weight slices in
+// flight, and the narrow column tile gives fc2-shaped launches (N = hidden size) enough blocks to cover the chip.
+// MOE_GEMM_TILE="bm,bnw" (environment) forces a tile for experiments.
+struct TileChoice { int bm, bnw; };
+static TileChoice choose_tile(int epilogue, int max_rows, int G, int N) {
+    // Measured on MI355X with cold weights (tools/tile_sweep.py, StableLM block, 5 layers cycled).  Below ~1k rows per
+    // group the launch is a weight stream and a CU draws only ~25 GB/s from HBM, so what counts is that every CU has a
+    // block and that the blocks come in few, even rounds: one row tile per group where possible, and for the
+    // non-gated GEMMs the widest column tile that still gives >= 128 blocks.  The gated fc1 has >= 160 column tiles
+    // already; narrower tiles only added rounds there.
+    const int rows_hint = (max_rows + G - 1) / G;
+    TileChoice t;
+    t.bm = rows_hint <= 32 ? 32 : rows_hint <= 64 ? 64 : rows_hint <= 512 ? 128 : 256;
+    t.bnw = 256;
+    if (epilogue == MOE_EPI_SWIGLU) {
+        if (t.bm < 64) t.bm = 64;
+    } else {
+        const long long row_tiles = (max_rows + t.bm - 1) / t.bm;
+        if (row_tiles * ((N + 255) / 256) < 128) t.bnw = row_tiles * ((N + 127) / 128) >= 128 ? 128 : 64;
+    }
+    if (const char *env = getenv("MOE_GEMM_TILE")) {
+        int bm = 0, bnw = 0;
+        if (sscanf(env, "%d,%d", &bm, &bnw) == 2) {
+            if (bm == 256 || bm == 128 || bm == 64 || bm == 32) t.bm = bm;
+            if (bnw == 256 || bnw == 128 || (bnw == 64 && epilogue != MOE_EPI_SWIGLU)) t.bnw = bnw;
+        }
+    }
+    return t;
+}
+
+template <int EPI, int BM, int BNW>
+static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
+    constexpr int NC = Tile<EPI, BM, BNW>::NC;
+    if (p.k_offsets) p.max_row_tiles = p.G * ((p.rows_per_group + BM - 1) / BM);
+    else p.max_row_tiles = max_rows_or_neg / BM + p.G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
+    p.col_tiles = (p.N_out + NC - 1) / NC;
+    const long long grid = (long long)p.max_row_tiles * p.col_tiles;
     if (grid <= 0) return 0;
-    hipLaunchKernelGGL((grouped_gemm_kernel<EPI>), dim3(grid), dim3(NTHREADS), 0, st, p);
+    if (grid > 0x7fffffffLL) return fail(MOE_ERR_SHAPE, "grouped_gemm: grid too large");
+    hipLaunchKernelGGL((grouped_gemm_kernel<EPI, BM, BNW>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, p);
     return check_launch("grouped_gemm_kernel");
+}
+
+template <int EPI>
+static int launch_gemm(GemmParams &p, int max_rows, TileChoice t, hipStream_t st) {
+    if (EPI != EPI_SWIGLU && t.bnw == 64) {
+        constexpr int E2 = EPI == EPI_SWIGLU ? EPI_PLAIN : EPI;  // keeps the SWIGLU x 64 combination uninstantiated
+        switch (t.bm) {
+            case 256: return launch_tile<E2, 256, 64>(p, max_rows, st);
+            case 128: return launch_tile<E2, 128, 64>(p, max_rows, st);
+            case 64: return launch_tile<E2, 64, 64>(p, max_rows, st);
+            default: return launch_tile<E2, 32, 64>(p, max_rows, st);
+        }
+    }
+    if (t.bnw == 128) {
+        switch (t.bm) {
+            case 256: return launch_tile<EPI, 256, 128>(p, max_rows, st);
+            case 128: return launch_tile<EPI, 128, 128>(p, max_rows, st);
+            case 64: return launch_tile<EPI, 64, 128>(p, max_rows, st);
+            default: return launch_tile<EPI, 32, 128>(p, max_rows, st);
+        }
+    }
+    switch (t.bm) {
+        case 256: return launch_tile<EPI, 256, 256>(p, max_rows, st);
+        case 128: return launch_tile<EPI, 128, 256>(p, max_rows, st);
+        case 64: return launch_tile<EPI, 64, 256>(p, max_rows, st);
+        default: return launch_tile<EPI, 32, 256>(p, max_rows, st);
+    }
 }
 
 }  // namespace moe
@@ -442,19 +527,17 @@ extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, co
     p.ldw = K;
     p.k_offsets = nullptr;
     p.rows_per_group = 0;
-    p.max_row_tiles = max_rows / BM + G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
     hipStream_t st = (hipStream_t)stream;
+    const TileChoice t = choose_tile(epilogue, max_rows, G, N);
     if (epilogue == MOE_EPI_SWIGLU) {
         p.w_expert_stride = 2ll * N * K;
         p.bias_expert_stride = 2ll * N;
-        p.col_tiles = (N + BNW / 2 - 1) / (BNW / 2);
-        return launch_gemm<EPI_SWIGLU>(p, st);
+        return launch_gemm<EPI_SWIGLU>(p, max_rows, t, st);
     }
     p.w_expert_stride = (long long)N * K;
     p.bias_expert_stride = N;
-    p.col_tiles = (N + BNW - 1) / BNW;
-    if (epilogue == MOE_EPI_GELU_NEW) return launch_gemm<EPI_GELU_NEW>(p, st);
-    return launch_gemm<EPI_PLAIN>(p, st);
+    if (epilogue == MOE_EPI_GELU_NEW) return launch_gemm<EPI_GELU_NEW>(p, max_rows, t, st);
+    return launch_gemm<EPI_PLAIN>(p, max_rows, t, st);
 }
 
 extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
@@ -500,9 +583,8 @@ static int launch_wgrad(const bf16_t *a_t, const bf16_t *w_t, long long ldk, con
     p.ldw = ldk;
     p.k_offsets = k_offsets;
     p.rows_per_group = R;
-    p.max_row_tiles = n_experts * ((R + BM - 1) / BM);
-    p.col_tiles = (N + BNW - 1) / BNW;
-    return launch_gemm<EPI_PLAIN>(p, st);
+    const TileChoice t = choose_tile(MOE_EPI_PLAIN, n_experts * R, n_experts, N);
+    return launch_gemm<EPI_PLAIN>(p, 0, t, st);
 }
 
 extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,

@@ -26,7 +26,7 @@ CONFIGS = {
 }
 
 
-def run(name, iters, warmup):
+def run(name, iters, warmup, n_layers):
     ctor, M, I, E, cf, S, training = CONFIGS[name]
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -36,23 +36,29 @@ def run(name, iters, warmup):
         p.data.normal_(0, 0.02)
     moe.deepspeed_moe.gate.wg.weight.data.normal_(0, 0.02)
     moe = moe.to(dev).train(training)
+    # the model has 12 MoE layers: cycling several copies keeps one layer's weights from sitting in the 256 MiB
+    # Infinity Cache between calls (which would flatter the weight-streaming configs)
+    import copy
+    layers = [moe] + [copy.deepcopy(moe) for _ in range(n_layers - 1)]
     x = torch.randn(1, S, M, device=dev).to(torch.bfloat16)
     with torch.no_grad():
-        for _ in range(warmup):
-            moe(x)
+        for i in range(max(warmup, n_layers)):
+            layers[i % n_layers](x)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            moe(x)
+        for i in range(iters):
+            layers[i % n_layers](x)
         e1.record()
         torch.cuda.synchronize()
         total = e0.elapsed_time(e1) / iters
         t = ops.PhaseTimer()
-        moe.deepspeed_moe.timer = t
-        for _ in range(iters):
-            moe(x)
-        moe.deepspeed_moe.timer = None
+        for m in layers:
+            m.deepspeed_moe.timer = t
+        for i in range(iters):
+            layers[i % n_layers](x)
+        for m in layers:
+            m.deepspeed_moe.timer = None
         ph = {k: statistics.mean(t.durations(a, b)) for k, (a, b) in
               {"gate+route": ("gate_begin", "gate_end"), "fc1": ("fc1_begin", "fc1_end"),
                "fc2": ("fc1_end", "fc2_end"), "combine": ("fc2_end", "combine_end")}.items()}
@@ -69,6 +75,7 @@ if __name__ == "__main__":
     ap.add_argument("configs", nargs="*", default=list(CONFIGS))
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--layers", type=int, default=4, help="distinct weight sets cycled (cold weights)")
     a = ap.parse_args()
     for c in a.configs:
-        run(c, a.iters, a.warmup)
+        run(c, a.iters, a.warmup, a.layers)
