@@ -5,7 +5,8 @@
 //   gate backward         dwg = dlogits^T @ float(x)                                              (F.linear backward)
 //   dispatch backward     dx[s] = sum_j dXrows[pos(s,j)] + dlogits[s] @ wg                         (einsum "sec,sm->ecm")
 //   activation fwd / bwd  over the compact rows (training keeps the pre-activation fc1 output)
-//   transposes            K-contiguous operands for the dgrad / wgrad launches of the grouped NT GEMM
+//   weight transposes     K-contiguous W^T for the data-gradient launches of the grouped NT GEMM (the weight
+//                         gradients read their operands untransposed: moe_wgrad.hip)
 //   bias gradient         per-expert column sums
 //
 // All kernels stream whole rows, 16 B per lane; they are HBM-bound.  Row counts that depend on the routing stay on
@@ -350,68 +351,23 @@ __global__ __launch_bounds__(256) void dispatch_bwd_kernel(const bf16_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// transposes: rows of group g -> K range [k_group[g], k_group[g] + roundup64(rows_g)) of a [C, ldk] image
+// batched transpose of the expert weights (K-contiguous operands for the data-gradient launches of the NT GEMM)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_offsets_kernel(const int *__restrict__ group_offsets, int G, int El, int *__restrict__ k_group,
-                                 int *__restrict__ k_expert) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int per = G / El;  // groups per local expert (ep sources)
-    int acc = 0;
-    for (int q = 0; q < G; ++q) {
-        const int le = q / per, src = q - le * per;
-        const int g = src * El + le;
-        if (src == 0) k_expert[le] = acc;
-        k_group[g] = acc;
-        const int rows = group_offsets[g + 1] - group_offsets[g];
-        acc += (rows + 63) & ~63;
-    }
-    k_expert[El] = acc;
-}
-
 constexpr int TR = 128;      // rows (K) per transpose tile
 constexpr int TC = 64;       // columns per transpose tile
 constexpr int TPITCH = 72;   // LDS row pitch in elements (144 B: 16-byte aligned rows)
 
-// uniform_rows > 0: batched plain transpose (group b = rows [b*R, (b+1)*R), destination image b at dst + b*C*R, ldk = R)
-__global__ __launch_bounds__(256) void transpose_rows_kernel(const bf16_t *__restrict__ src, long long lds_,
-                                                             const int *__restrict__ gather, int gather_shift,
-                                                             const int *__restrict__ group_offsets, int G,
-                                                             const int *__restrict__ k_group, int uniform_rows, int C,
+// dst[b, c, r] = src[b, r, c]: batch b = rows [b*R, (b+1)*R) of src, destination image b at dst + b*C*R, row stride R
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const bf16_t *__restrict__ src, long long lds_, int B, int R, int C,
                                                              bf16_t *__restrict__ dst, long long ldk) {
     __shared__ __attribute__((aligned(16))) bf16_t tile[TR * TPITCH];
     const int rt = blockIdx.x;
-    int rb = 0, re = 0, k0 = 0;
-    long long kbase = 0;
-    bool found = false;
-    if (uniform_rows > 0) {
-        const int tpg = (uniform_rows + TR - 1) / TR;
-        const int g = rt / tpg;
-        if (g < G) {
-            found = true;
-            rb = g * uniform_rows;
-            re = rb + uniform_rows;
-            k0 = (rt - g * tpg) * TR;
-            kbase = (long long)g * C * uniform_rows;
-        }
-    } else {
-        int tile0 = 0;
-        for (int g = 0; g < G; ++g) {
-            const int b = group_offsets[g], e = group_offsets[g + 1];
-            const int padded = (e - b + 63) & ~63;
-            const int nt = (padded + TR - 1) / TR;
-            if (rt < tile0 + nt) {
-                found = true;
-                rb = b;
-                re = e;
-                k0 = (rt - tile0) * TR;
-                kbase = k_group[g];
-                break;
-            }
-            tile0 += nt;
-        }
-    }
-    if (!found) return;
-    const int padded = (re - rb + 63) & ~63;
+    const int tpg = (R + TR - 1) / TR;
+    const int g = rt / tpg;
+    if (g >= B) return;
+    const int rb = g * R, re = rb + R;
+    const int k0 = (rt - g * tpg) * TR;
+    const long long kbase = (long long)g * C * R;
     const int c0 = blockIdx.y * TC;
     const int tid = threadIdx.x;
 #pragma unroll
@@ -420,10 +376,7 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const bf16_t *__res
         const int row = q >> 3, ch = q & 7;
         const int r = rb + k0 + row;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (r < re && c0 + ch * 8 < C) {
-            const long long srow = gather ? (long long)(gather[r] >> gather_shift) : (long long)r;
-            v = *reinterpret_cast<const uint4 *>(src + srow * lds_ + c0 + ch * 8);
-        }
+        if (r < re && c0 + ch * 8 < C) v = *reinterpret_cast<const uint4 *>(src + (long long)r * lds_ + c0 + ch * 8);
         *reinterpret_cast<uint4 *>(tile + row * TPITCH + ch * 8) = v;
     }
     __syncthreads();
@@ -431,7 +384,7 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const bf16_t *__res
     for (int i = 0; i < 4; ++i) {
         const int q = tid + i * 256;
         const int c = q >> 4, kc = q & 15;
-        if (k0 + kc * 8 < padded && c0 + c < C) {
+        if (k0 + kc * 8 < R && c0 + c < C) {  // R % 8 == 0
             unsigned short e[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) e[j] = tile[(kc * 8 + j) * TPITCH + c];
@@ -490,24 +443,9 @@ static inline int ew_grid(long long items) {
     return (int)(b > 65536 ? 65536 : b);
 }
 
-int launch_k_offsets(const int *group_offsets, int G, int El, int *k_group, int *k_expert, hipStream_t st) {
-    hipLaunchKernelGGL(k_offsets_kernel, dim3(1), dim3(64), 0, st, group_offsets, G, El, k_group, k_expert);
-    return check_launch("k_offsets_kernel");
-}
-
-int launch_transpose_rows(const bf16_t *src, long long lds_, const int *gather, int gather_shift, const int *group_offsets,
-                          int G, const int *k_group, int max_rows, int C, bf16_t *dst, long long ldk, hipStream_t st) {
-    const int tiles = (max_rows + 64 * G) / TR + G;
-    dim3 grid(tiles, (C + TC - 1) / TC);
-    hipLaunchKernelGGL(transpose_rows_kernel, grid, dim3(256), 0, st, src, lds_, gather, gather_shift, group_offsets, G, k_group,
-                       0, C, dst, ldk);
-    return check_launch("transpose_rows_kernel");
-}
-
 int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst, hipStream_t st) {
     dim3 grid(B * ((R + TR - 1) / TR), (C + TC - 1) / TC);
-    hipLaunchKernelGGL(transpose_rows_kernel, grid, dim3(256), 0, st, src, (long long)C, (const int *)nullptr, 0,
-                       (const int *)nullptr, B, (const int *)nullptr, R, C, dst, (long long)R);
+    hipLaunchKernelGGL(transpose_rows_kernel, grid, dim3(256), 0, st, src, (long long)C, B, R, C, dst, (long long)R);
     return check_launch("transpose_rows_kernel(batched)");
 }
 

@@ -84,14 +84,11 @@ __device__ __forceinline__ float gelu_new_bf16(float x) {
 }
 
 // ---- helpers of the backward pass implemented in moe_backward.hip, used by moe_expert_ffn_bwd ----
-// K-order layout of the transposed activations: group g = (src, le) goes to K slot le*(G/El)+src, every group padded
-// with zeros to a multiple of 64 rows; k_group[g] = first K index of group g, k_expert[le] = first K index of expert le.
-int launch_k_offsets(const int *group_offsets, int G, int n_experts_local, int *k_group, int *k_expert, hipStream_t st);
-// dst[c, k_group[g] + (r - group_offsets[g])] = src[row(r), c] for the rows of every group, zero padding included.
-int launch_transpose_rows(const bf16_t *src, long long lds, const int *gather, int gather_shift, const int *group_offsets,
-                          int G, const int *k_group, int max_rows, int C, bf16_t *dst, long long ldk, hipStream_t st);
 // dst[b, c, r] = src[b, r, c]
 int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst, hipStream_t st);
+// dW_e[R, N] = A[rows of expert e]^T @ B[rows of expert e] (moe_wgrad.hip)
+int launch_wgrad_tn(const bf16_t *a, long long lda, const bf16_t *b, long long ldb, const int *group_offsets, int G,
+                    int n_experts, int R, int N, bf16_t *out, hipStream_t st);
 int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, int n_gated, bf16_t *h,
                    hipStream_t st);
 int launch_act_bwd(int act, const bf16_t *ab, const bf16_t *dh, const int *n_rows_dev, int max_rows, int I, int n_gated,

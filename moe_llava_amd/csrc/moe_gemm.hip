@@ -57,11 +57,6 @@ struct GemmParams {
     int n_gated;       // gated: output columns >= n_gated bypass SiLU (RePaMLP mask); = N_out for plain SwiGLU
     int max_row_tiles;
     int col_tiles;
-    // weight-gradient mode (k_offsets != nullptr): group g is expert g with rows_per_group output rows; both operands
-    // are K-contiguous transposed images and expert g contracts over K range [k_offsets[g], k_offsets[g+1])
-    long long ldw;         // row stride of W (= K in the forward layout)
-    const int *k_offsets;
-    int rows_per_group;
 };
 
 __device__ __forceinline__ void glds16(const bf16_t *gsrc, bf16_t *lds_wave_base) {
@@ -139,15 +134,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 
     // ---- row tile -> group (expert), row range ----
     int row_begin = 0, row_end = 0, grp = -1;
-    if (p.k_offsets) {
-        const int tpg = (p.rows_per_group + BM - 1) / BM;
-        const int g = rt / tpg;
-        if (g < p.G) {
-            grp = g;
-            row_begin = g * p.rows_per_group + (rt - g * tpg) * BM;
-            row_end = (g + 1) * p.rows_per_group;
-        }
-    } else {
+    {
         int tile0 = 0;
         for (int g = 0; g < p.G; ++g) {
             const int b = p.group_offsets[g], e = p.group_offsets[g + 1];
@@ -163,10 +150,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     }
     if (grp < 0) return;  // surplus block of the worst-case grid (uniform per block)
     const int expert = grp % p.n_experts;
-    const int k_first = p.k_offsets ? p.k_offsets[grp] : 0;
-    const bf16_t *wbase = p.w + (long long)expert * p.w_expert_stride + k_first;
-    const bf16_t *abase = p.a + k_first;
-    const int a_row0 = p.k_offsets ? grp * p.rows_per_group : 0;  // wgrad: A rows are local to the expert
+    const bf16_t *wbase = p.w + (long long)expert * p.w_expert_stride;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -201,8 +185,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             const int cs = c ^ xsw(row);
             int prow = row_begin + row;
             if (prow > row_end - 1) prow = row_end - 1;  // clamp: rows past the group end are never stored
-            const long long srow = p.gather ? (long long)(p.gather[prow] >> p.gather_shift) : (long long)(prow - a_row0);
-            a_src[j] = abase + srow * p.lda + cs * 8;
+            const long long srow = p.gather ? (long long)(p.gather[prow] >> p.gather_shift) : (long long)prow;
+            a_src[j] = p.a + srow * p.lda + cs * 8;
         }
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
@@ -217,11 +201,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             } else {
                 wrow = min(ct * BNW + row, p.N_out - 1);
             }
-            w_src[j] = wbase + (long long)wrow * p.ldw + cs * 8;
+            w_src[j] = wbase + (long long)wrow * p.K + cs * 8;
         }
     }
     bf16_t *const lds_e = reinterpret_cast<bf16_t *>(lds);
-    const int nk = p.k_offsets ? (p.k_offsets[grp + 1] - k_first) / BK : p.K / BK;  // K % 64 == 0; wgrad: may be 0
+    const int nk = p.K / BK;  // >= 1 (K % 64 == 0)
     auto stage = [&](int buf, int kt) {
         if (!loader) return;
         bf16_t *slot = lds_e + buf * T::SLOT_ELEMS;
@@ -439,8 +423,7 @@ static TileChoice choose_tile(int epilogue, int max_rows, int G, int N) {
 template <int EPI, int BM, int BNW>
 static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     constexpr int NC = Tile<EPI, BM, BNW>::NC;
-    if (p.k_offsets) p.max_row_tiles = p.G * ((p.rows_per_group + BM - 1) / BM);
-    else p.max_row_tiles = max_rows_or_neg / BM + p.G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
+    p.max_row_tiles = max_rows_or_neg / BM + p.G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
     p.col_tiles = (p.N_out + NC - 1) / NC;
     const long long grid = (long long)p.max_row_tiles * p.col_tiles;
     if (grid <= 0) return 0;
@@ -524,9 +507,6 @@ extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, co
     p.N_out = N;
     p.b_row_offset = N;
     p.n_gated = (n_gated < 0 || n_gated > N) ? N : n_gated;
-    p.ldw = K;
-    p.k_offsets = nullptr;
-    p.rows_per_group = 0;
     hipStream_t st = (hipStream_t)stream;
     const TileChoice t = choose_tile(epilogue, max_rows, G, N);
     if (epilogue == MOE_EPI_SWIGLU) {
@@ -558,35 +538,6 @@ extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int
                                 -1, y, M, stream);
 }
 
-// out[e] ([R, N] bf16) = A_t[:, Ke] @ W_t[:, Ke]^T with Ke = [k_offsets[e], k_offsets[e+1]): the weight gradient of one
-// Linear for every local expert, both operands as K-contiguous transposed images of row stride ldk.
-static int launch_wgrad(const bf16_t *a_t, const bf16_t *w_t, long long ldk, const int *k_offsets, int n_experts, int R, int N,
-                        bf16_t *out, hipStream_t st) {
-    GemmParams p;
-    p.a = a_t;
-    p.lda = ldk;
-    p.gather = nullptr;
-    p.gather_shift = 0;
-    p.w = w_t;
-    p.w_expert_stride = 0;
-    p.bias = nullptr;
-    p.bias_expert_stride = 0;
-    p.group_offsets = nullptr;
-    p.G = n_experts;
-    p.n_experts = n_experts;
-    p.out = out;
-    p.ldo = N;
-    p.K = 0;
-    p.N_out = N;
-    p.b_row_offset = N;
-    p.n_gated = N;
-    p.ldw = ldk;
-    p.k_offsets = k_offsets;
-    p.rows_per_group = R;
-    const TileChoice t = choose_tile(MOE_EPI_PLAIN, n_experts * R, n_experts, N);
-    return launch_gemm<EPI_PLAIN>(p, 0, t, st);
-}
-
 extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                         const void *w1, const void *b1, const void *w2, const void *b2,
                                         const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
@@ -613,16 +564,13 @@ extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, con
 
 namespace {
 struct BwdWs {
-    int *k_group, *k_expert;
-    bf16_t *wt, *dh, *dab, *ta, *tb;
-    long long ldk;
+    bf16_t *wt, *dh, *dab, *xr;
     size_t total;
 };
 inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 BwdWs carve_bwd(void *ws, int act, int G, int El, int max_rows, int M, int I) {
     const size_t N1 = act == MOE_ACT_SWIGLU ? 2 * (size_t)I : (size_t)I;
     BwdWs r;
-    r.ldk = (((long long)max_rows + 63) & ~63ll) + 64ll * G;
     char *base = (char *)ws;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -630,14 +578,12 @@ BwdWs carve_bwd(void *ws, int act, int G, int El, int max_rows, int M, int I) {
         off += pad256(bytes);
         return ptr;
     };
-    r.k_group = (int *)take(sizeof(int) * (size_t)G);
-    r.k_expert = (int *)take(sizeof(int) * ((size_t)El + 1));
-    r.wt = (bf16_t *)take(2 * (size_t)El * M * N1);
+    r.wt = (bf16_t *)take(2 * (size_t)El * M * N1);        // W2^T, then W1^T
     r.dh = (bf16_t *)take(2 * (size_t)max_rows * I);
     r.dab = (bf16_t *)take(2 * (size_t)max_rows * N1);
-    r.ta = (bf16_t *)take(2 * (N1 > (size_t)M ? N1 : (size_t)M) * (size_t)r.ldk);
-    r.tb = (bf16_t *)take(2 * ((size_t)I > (size_t)M ? (size_t)I : (size_t)M) * (size_t)r.ldk);
+    r.xr = (bf16_t *)take(2 * (size_t)max_rows * M);       // gathered input rows (only when a gather index is given)
     r.total = off;
+    (void)G;
     return r;
 }
 }  // namespace
@@ -669,17 +615,13 @@ extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int
     const int N1 = act == MOE_ACT_SWIGLU ? 2 * I : I;
     const bf16_t *dyp = (const bf16_t *)dy;
     int rc;
-    if ((rc = launch_k_offsets(group_offsets, G, El, ws.k_group, ws.k_expert, st))) return rc;
     // ---- fc2: dH = dY @ W2, dW2 = dY^T @ H, db2 = colsum(dY) ----
     if ((rc = launch_transpose_batched((const bf16_t *)w2, El, M, I, ws.wt, st))) return rc;  // W2^T [El, I, M]
     if ((rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, dy, M, nullptr, 0, ws.wt, nullptr, group_offsets, G, El, max_rows, M, I,
                                    -1, ws.dh, I, stream)))
         return rc;
-    if ((rc = launch_transpose_rows(dyp, M, nullptr, 0, group_offsets, G, ws.k_group, max_rows, M, ws.ta, ws.ldk, st))) return rc;
-    if ((rc = launch_transpose_rows((const bf16_t *)h, I, nullptr, 0, group_offsets, G, ws.k_group, max_rows, I, ws.tb, ws.ldk,
-                                    st)))
+    if ((rc = launch_wgrad_tn(dyp, M, (const bf16_t *)h, I, group_offsets, G, El, M, I, (bf16_t *)dw2, st)))
         return rc;
-    if ((rc = launch_wgrad(ws.ta, ws.tb, ws.ldk, ws.k_expert, El, M, I, (bf16_t *)dw2, st))) return rc;
     if (db2 && (rc = launch_bias_grad(dyp, group_offsets, G, El, max_rows, M, db2, st))) return rc;
     // ---- activation ----
     if (max_rows > 0 &&
@@ -690,12 +632,16 @@ extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int
     if ((rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, ws.dab, N1, nullptr, 0, ws.wt, nullptr, group_offsets, G, El, max_rows, N1,
                                    M, -1, da_rows, M, stream)))
         return rc;
-    if ((rc = launch_transpose_rows(ws.dab, N1, nullptr, 0, group_offsets, G, ws.k_group, max_rows, N1, ws.ta, ws.ldk, st)))
-        return rc;
-    if ((rc = launch_transpose_rows((const bf16_t *)a, lda, gather, gather_shift, group_offsets, G, ws.k_group, max_rows, M,
-                                    ws.tb, ws.ldk, st)))
-        return rc;
-    if ((rc = launch_wgrad(ws.ta, ws.tb, ws.ldk, ws.k_expert, El, N1, M, (bf16_t *)dw1, st))) return rc;
+    const bf16_t *xrows = (const bf16_t *)a;
+    long long ldx = lda;
+    if (gather) {  // the weight-gradient kernel streams plain rows: materialise the gathered input once (rows * M * 2 B)
+        if (max_rows > 0 &&
+            (rc = moe_gather_rows_fwd(a, gather, gather_shift, group_offsets + G, max_rows, M, ws.xr, stream)))
+            return rc;
+        xrows = ws.xr;
+        ldx = M;
+    }
+    if ((rc = launch_wgrad_tn(ws.dab, N1, xrows, ldx, group_offsets, G, El, N1, M, (bf16_t *)dw1, st))) return rc;
     if (db1 && (rc = launch_bias_grad(ws.dab, group_offsets, G, El, max_rows, N1, db1, st))) return rc;
     return 0;
 }

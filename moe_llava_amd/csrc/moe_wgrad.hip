@@ -1,0 +1,248 @@
+// Weight-gradient GEMM of the expert Linears for gfx950:
+//   dW_e[r, n] = sum over the rows k of expert e of A[k, r] * B[k, n]          (dW2 = dY^T H,  dW1 = dAB^T X)
+// Both operands are ROW-major in k (the compact activation rows), i.e. "transposed" for an MFMA that wants 8
+// consecutive k per lane.  Instead of transposing them in HBM, the tiles go to LDS as they are -- [64 k][256 cols],
+// filled by global_load_lds_dwordx4 (one 1-KiB piece = 2 k-rows) -- and the fragments are read with gfx950's
+// ds_read_b64_tr_b16, which hands each lane 4 consecutive k of one column: two of them make the 8-k operand of
+// v_mfma_f32_16x16x32_bf16.  A 16-byte-chunk XOR keyed on the k row (applied to the per-lane SOURCE address of the
+// LDS-DMA and again on the read) spreads the 8 k-rows a 32-lane half touches over the 64 banks.
+// The last K slice of an expert clamps its rows to the expert's last row and the rows past the end are zeroed in LDS,
+// so no padding of K is needed.
+//
+// Tile 256 (r) x 256 (n) x 64 (k), 512 threads = 8 waves as 2 x 4, wave tile 128 x 64, 2 x 64 KiB ring, epilogue and
+// block -> tile remap as in moe_gemm.hip.  MFMA-bound: 2 * rows * R * N flop per launch.
+#include "moe_common.h"
+
+namespace moe {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int WT = 256;   // tile edge (both output dims)
+constexpr int WBK = 64;   // k rows per slice
+constexpr int WTHREADS = 512;
+constexpr int W_SLOT_ELEMS = 2 * WBK * WT;                    // A tile + B tile
+constexpr int W_EPI_ROWB = WT * 2 + 16;
+constexpr int W_LDS_BYTES = WT * W_EPI_ROWB;                  // 135168 >= 2 slots x 64 KiB
+
+struct WgradParams {
+    const bf16_t *a;   // [rows, R] row stride lda
+    long long lda;
+    const bf16_t *b;   // [rows, N] row stride ldb
+    long long ldb;
+    const int *group_offsets;  // [G+1]; groups of expert e: e, e + El, e + 2 El, ... (contiguous when G == El)
+    int G;
+    int n_experts;
+    int R, N;
+    bf16_t *out;       // [n_experts, R, N]
+    int r_tiles, n_tiles;
+};
+
+__device__ __forceinline__ void glds16w(const bf16_t *gsrc, bf16_t *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(gsrc)),
+        reinterpret_cast<__attribute__((address_space(3))) void *>(
+            static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_wave_base))),
+        16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier_w() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// chunk swizzle key of k row k (16-byte chunks, even values keep the two chunks of a 32-byte run adjacent)
+__device__ __forceinline__ int ksw(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
+
+__global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[W_LDS_BYTES];
+
+    // ---- block -> (expert, r tile, n tile): XCD-contiguous chunks ----
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    // inside an expert: super-rows of 4 r tiles, n tile next, r tile fastest -> the ~32 blocks an XCD runs together
+    // share 4 A panels and 8 B panels in its L2
+    const int per_e = p.r_tiles * p.n_tiles;
+    const int expert = swz / per_e;
+    const int rem = swz - expert * per_e;
+    const int per_sr = 4 * p.n_tiles;
+    const int sr = rem / per_sr;
+    const int rem2 = rem - sr * per_sr;
+    const int rows_in = min(4, p.r_tiles - sr * 4);
+    const int nt = rem2 / rows_in;
+    const int rt = sr * 4 + (rem2 - nt * rows_in);
+    if (expert >= p.n_experts) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf) acc[nf][mf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging: piece q (0..31) of a tile = k rows 2q, 2q+1; lane -> k row 2q + (lane >> 5), LDS chunk lane & 31,
+    //      which holds source chunk (lane & 31) ^ ksw(k).  Waves 0..3 issue 8 pieces of each operand per slice.
+    //      For piece q = lwave*8 + j the key ksw(k) depends on j only through (j & 1) and (j >> 2): 4 column offsets. ----
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) < 4;
+    const int lwave = wave & 3;
+    const int kl = lane >> 5;
+    int a_col[4], b_col[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j0 = (t & 1) | ((t >> 1) << 2);
+        const int cs = (lane & 31) ^ ksw((lwave * 8 + j0) * 2 + kl);
+        // columns past the matrix edge are clamped (their products land in output columns that are never stored)
+        a_col[t] = min(rt * WT + cs * 8, p.R - 8) * 2;  // bytes
+        b_col[t] = min(nt * WT + cs * 8, p.N - 8) * 2;
+    }
+    char *const lds_b = lds;
+
+    // ---- fragment reads.  Lane (group fq, l = fr = 4 tq + tp) supplies row k0 + tq, columns c0 + 4 tp .. + 3 of a
+    //      4 x 16 block; it receives column c0 + fr, rows k0 .. k0 + 3.  The swizzle key of the rows a lane supplies,
+    //      ksw(ks*32 + fq*8 + tq (+4)), is the same for every ks and both halves, so each fragment has ONE per-lane
+    //      base (bytes inside a slot) and the k steps are immediates: + ks*16384 + half*2048. ----
+    const int tq = fr >> 2, tp = fr & 3;
+    const int key = (tq | ((fq & 1) << 2)) << 1;
+    int xb[8], wb[4];
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf)
+        xb[mf] = (fq * 8 + tq) * (WT * 2) + (((wm * 16 + mf * 2 + (tp >> 1)) ^ key) << 4) + ((tp & 1) << 3);
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+        wb[nf] = WBK * WT * 2 + (fq * 8 + tq) * (WT * 2) + (((wn * 8 + nf * 2 + (tp >> 1)) ^ key) << 4) + ((tp & 1) << 3);
+    auto tr8 = [&](const char *base, int off) {
+        typedef __attribute__((address_space(3))) s16x4_t *lp_t;
+        const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>(base));
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lp_t>(addr + off));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lp_t>(addr + off + 4 * WT * 2));
+        const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8_t, v);
+    };
+
+    // the groups of this expert: e, e + El, ... ; each is a K range of its own (expert-parallel receive layout)
+    const int per = p.G / p.n_experts;
+    for (int src = 0; src < per; ++src) {
+        const int g = src * p.n_experts + expert;
+        const int k_first = p.group_offsets[g];
+        const int nrows = p.group_offsets[g + 1] - k_first;
+        const int nk = (nrows + WBK - 1) / WBK;
+        if (nk == 0) continue;
+        // Sources as uniform base + 32-bit lane offset (bytes): one v_add3 per piece in the steady state.  The last
+        // slice clamps its rows to the group's last row (in bounds) and the rows past the end are zeroed in LDS below.
+        const char *abase = reinterpret_cast<const char *>(p.a + (long long)k_first * p.lda);
+        const char *bbase = reinterpret_cast<const char *>(p.b + (long long)k_first * p.ldb);
+        const unsigned lda_b = (unsigned)p.lda * 2u, ldb_b = (unsigned)p.ldb * 2u;
+        auto stage = [&](int buf, int kt) {
+            if (!loader) return;
+            bf16_t *slot = reinterpret_cast<bf16_t *>(lds_b) + buf * W_SLOT_ELEMS + lwave * 8 * 512;
+            const unsigned row0 = (unsigned)(kt * WBK + lwave * 16 + kl);
+            if (kt + 1 < nk) {
+                const unsigned ra = row0 * lda_b, rb = row0 * ldb_b;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = (j & 1) | ((j >> 2) << 1);
+                    glds16w(reinterpret_cast<const bf16_t *>(abase + (ra + (unsigned)(2 * j) * lda_b + (unsigned)a_col[t])),
+                            slot + j * 512);
+                    glds16w(reinterpret_cast<const bf16_t *>(bbase + (rb + (unsigned)(2 * j) * ldb_b + (unsigned)b_col[t])),
+                            slot + WBK * WT + j * 512);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = (j & 1) | ((j >> 2) << 1);
+                    const unsigned r = min(row0 + (unsigned)(2 * j), (unsigned)(nrows - 1));
+                    glds16w(reinterpret_cast<const bf16_t *>(abase + (r * lda_b + (unsigned)a_col[t])), slot + j * 512);
+                    glds16w(reinterpret_cast<const bf16_t *>(bbase + (r * ldb_b + (unsigned)b_col[t])),
+                            slot + WBK * WT + j * 512);
+                }
+            }
+        };
+        __syncthreads();  // previous group's last slice is fully consumed before the ring is reused
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vm_barrier_w<0>();
+#ifndef WG_NO_LOAD
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+#endif
+            const char *lb = lds_b + (kt & 1) * (W_SLOT_ELEMS * 2);
+            if (kt == nk - 1 && (nrows & (WBK - 1))) {
+                // zero the k rows past the group's end in both tiles (they hold a copy of the last row), then re-sync
+                const int rem = nrows & (WBK - 1);
+                char *wlb = lds_b + (kt & 1) * (W_SLOT_ELEMS * 2);
+                for (int i = tid; i < (WBK - rem) * 64; i += WTHREADS) {
+                    const int row = rem + (i >> 6), ch = i & 63;  // 64 chunks: 32 of the A tile row, 32 of the B tile row
+                    char *dst = wlb + (ch >> 5) * (WBK * WT * 2) + row * (WT * 2) + (ch & 31) * 16;
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(0u, 0u, 0u, 0u);
+                }
+                __syncthreads();
+            }
+#ifndef WG_NO_MFMA
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t xf[8], wf[4];
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) wf[nf] = tr8(lb, wb[nf] + ks * 32 * WT * 2);
+#pragma unroll
+                for (int mf = 0; mf < 8; ++mf) xf[mf] = tr8(lb, xb[mf] + ks * 32 * WT * 2);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 8; ++mf)
+                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+#endif
+        }
+    }
+
+    // ---- epilogue: bf16 tile image in LDS -> 16-byte full-line stores ----
+    __syncthreads();
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+        const int cl = wn * 64 + nf * 16 + fq * 4;
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf) {
+            uint2 o;
+            o.x = (unsigned)f2bf(acc[nf][mf][0]) | ((unsigned)f2bf(acc[nf][mf][1]) << 16);
+            o.y = (unsigned)f2bf(acc[nf][mf][2]) | ((unsigned)f2bf(acc[nf][mf][3]) << 16);
+            *reinterpret_cast<uint2 *>(lds + (wm * 128 + mf * 16 + fr) * W_EPI_ROWB + cl * 2) = o;
+        }
+    }
+    __syncthreads();
+    {
+        const int cc = tid & 31, r0 = tid >> 5;  // 32 chunks per row, 16 rows per pass
+        const int col = nt * WT + cc * 8;
+        if (col < p.N) {
+            for (int r = r0; r < WT; r += 16) {
+                const int row = rt * WT + r;
+                if (row < p.R) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(lds + r * W_EPI_ROWB + cc * 16);
+                    *reinterpret_cast<uint4 *>(p.out + ((long long)expert * p.R + row) * p.N + col) = v;
+                }
+            }
+        }
+    }
+}
+
+// out[e] ([R, N] bf16) = A[rows of e]^T @ B[rows of e];  R, N multiples of 8, >= 8
+int launch_wgrad_tn(const bf16_t *a, long long lda, const bf16_t *b, long long ldb, const int *group_offsets, int G,
+                    int n_experts, int R, int N, bf16_t *out, hipStream_t st) {
+    WgradParams p;
+    p.a = a; p.lda = lda; p.b = b; p.ldb = ldb;
+    p.group_offsets = group_offsets; p.G = G; p.n_experts = n_experts;
+    p.R = R; p.N = N; p.out = out;
+    p.r_tiles = (R + WT - 1) / WT;
+    p.n_tiles = (N + WT - 1) / WT;
+    const long long grid = (long long)n_experts * p.r_tiles * p.n_tiles;
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)grid), dim3(WTHREADS), 0, st, p);
+    return check_launch("wgrad_tn_kernel");
+}
+
+}  // namespace moe
