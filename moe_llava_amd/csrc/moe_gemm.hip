@@ -112,6 +112,9 @@ __device__ __forceinline__ void wait_vm_barrier() {
 template <int EPI, int BM, int BNW>
 __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmParams p) {
     using T = Tile<EPI, BM, BNW>;
+#ifdef GEMM_STAMPS
+    const unsigned long long st_entry = stamp();
+#endif
     constexpr int NS = T::NS, MF = T::MF, NF = T::NF, WNT = T::WNT, NC = T::NC, ROWB = T::ROWB;
     __shared__ __attribute__((aligned(16))) char lds[T::LDS_BYTES];
 
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         if (lane == 0 && blockIdx.x >= 1024 && blockIdx.x < 1032) {
             unsigned long long *o = g_stamps + ((blockIdx.x - 1024) * 8 + wave) * 8;
             o[0] = st_wait; o[1] = st_issue; o[2] = st_comp; o[3] = st_loop_end - st_begin; o[4] = st_end - st_loop_end;
-            o[5] = nk; o[6] = st_begin; o[7] = st_end;
+            o[5] = nk; o[6] = st_begin - st_entry; o[7] = st_end;
         }
     }
 #endif

@@ -12,9 +12,9 @@ buf = (ctypes.c_ulonglong * 512)()
 lib.moe_debug_read_stamps.argtypes = [ctypes.c_void_p]
 assert lib.moe_debug_read_stamps(buf) == 0
 a = np.array(buf, dtype=np.uint64).reshape(8, 8, 8)
-print("block wave  wait   issue  reads+mfma  loop   epilogue   nk   per-step(wait issue comp)")
+print("block wave  wait   issue  reads+mfma  loop   epilogue prologue  nk   per-step(wait issue comp)")
 for b in range(8):
     for w in range(8):
-        wt, iss, cp, loop, epi, nk = [int(v) for v in a[b, w, :6]]
+        wt, iss, cp, loop, epi, nk, pro = [int(v) for v in a[b, w, :7]]
         if nk == 0: continue
-        print(f"{b:3d} {w:3d} {wt:8d} {iss:7d} {cp:9d} {loop:8d} {epi:7d} {nk:4d}   {wt/nk:7.0f} {iss/nk:6.0f} {cp/nk:7.0f}")
+        print(f"{b:3d} {w:3d} {wt:8d} {iss:7d} {cp:9d} {loop:8d} {epi:7d} {pro:7d} {nk:4d}   {wt/nk:7.0f} {iss/nk:6.0f} {cp/nk:7.0f}")
