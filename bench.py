@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (704 tokens each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the informational forward+backward timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,6 +214,30 @@ def main():
                 roofline["traffic_unit"] = ("bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, "
                                             + os.path.relpath(pmc, ROOT) + ")")
                 roofline["algorithmic_bytes"] = 2.0 * (2 * I * M * E) + 2.0 * S * M + 2.0 * rows_local * I
+    # ---- informational: one training step (forward + backward through the autograd node) on the same batch; not part
+    #      of `value` (BASELINE's metric is the forward block) ----
+    training = None
+    if world == 1 and not args.no_train:
+        moe.train()
+        R = torch.randn_like(x)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        fw, bw = [], []
+        for i in range(2 + 5):
+            moe.zero_grad(set_to_none=True)
+            xg = x.detach().requires_grad_(True)
+            ev[0].record()
+            o, la, _ = moe(xg)
+            ev[1].record()
+            torch.autograd.backward([o, la], [R, torch.ones_like(la) * 0.01])
+            ev[2].record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                fw.append(ev[0].elapsed_time(ev[1]))
+                bw.append(ev[1].elapsed_time(ev[2]))
+        moe.zero_grad(set_to_none=True)
+        f, b = statistics.median(fw), statistics.median(bw)
+        training = {"fwd_ms": f, "bwd_ms": b, "tokens_per_s": S / (f + b) * 1e3,
+                    "note": "forward (keeping pre-activations) + backward of the block, 5 steps, HIP events"}
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -234,6 +259,7 @@ def main():
                        "kept_pairs_per_token": n_kept},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "training": training,
             "layer_tflops": (n_kept * 6.0 * M * I * S / (ms * 1e-3) / 1e12) if n_kept else None,
             "l_aux": float(l_aux), "exp_counts": exp_counts.tolist(),
         }

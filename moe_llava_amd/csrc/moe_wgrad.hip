@@ -89,14 +89,18 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
     // ---- staging: piece q (0..31) of a tile = k rows 2q, 2q+1; lane -> k row 2q + (lane >> 5), LDS chunk lane & 31,
     //      which holds source chunk (lane & 31) ^ ksw(k).  Waves 0..3 issue 8 pieces of each operand per slice.
     //      For piece q = lwave*8 + j the key ksw(k) depends on j only through (j & 1) and (j >> 2): 4 column offsets. ----
-    const bool loader = __builtin_amdgcn_readfirstlane(wave) < 4;
-    const int lwave = wave & 3;
+#ifndef WG_LW
+#define WG_LW 4
+#endif
+    constexpr int LW = WG_LW;          // loader waves
+    constexpr int NPL = 32 / LW;       // pieces of each operand per loader wave and slice
+    const bool loader = __builtin_amdgcn_readfirstlane(wave) < LW;
+    const int lwave = wave % LW;
     const int kl = lane >> 5;
     int a_col[4], b_col[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int j0 = (t & 1) | ((t >> 1) << 2);
-        const int cs = (lane & 31) ^ ksw((lwave * 8 + j0) * 2 + kl);
+        const int cs = (lane & 31) ^ ksw((t >> 1) * 8 + (t & 1) * 2 + kl);  // key of a k row with these bits
         // columns past the matrix edge are clamped (their products land in output columns that are never stored)
         a_col[t] = min(rt * WT + cs * 8, p.R - 8) * 2;  // bytes
         b_col[t] = min(nt * WT + cs * 8, p.N - 8) * 2;
@@ -140,13 +144,13 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
         const unsigned lda_b = (unsigned)p.lda * 2u, ldb_b = (unsigned)p.ldb * 2u;
         auto stage = [&](int buf, int kt) {
             if (!loader) return;
-            bf16_t *slot = reinterpret_cast<bf16_t *>(lds_b) + buf * W_SLOT_ELEMS + lwave * 8 * 512;
-            const unsigned row0 = (unsigned)(kt * WBK + lwave * 16 + kl);
+            bf16_t *slot = reinterpret_cast<bf16_t *>(lds_b) + buf * W_SLOT_ELEMS + lwave * NPL * 512;
+            const unsigned row0 = (unsigned)(kt * WBK + lwave * NPL * 2 + kl);
             if (kt + 1 < nk) {
                 const unsigned ra = row0 * lda_b, rb = row0 * ldb_b;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int t = (j & 1) | ((j >> 2) << 1);
+                for (int j = 0; j < NPL; ++j) {
+                    const int t = (j & 1) | ((((lwave * NPL + j) >> 2) & 1) << 1);
                     glds16w(reinterpret_cast<const bf16_t *>(abase + (ra + (unsigned)(2 * j) * lda_b + (unsigned)a_col[t])),
                             slot + j * 512);
                     glds16w(reinterpret_cast<const bf16_t *>(bbase + (rb + (unsigned)(2 * j) * ldb_b + (unsigned)b_col[t])),
@@ -154,8 +158,8 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int t = (j & 1) | ((j >> 2) << 1);
+                for (int j = 0; j < NPL; ++j) {
+                    const int t = (j & 1) | ((((lwave * NPL + j) >> 2) & 1) << 1);
                     const unsigned r = min(row0 + (unsigned)(2 * j), (unsigned)(nrows - 1));
                     glds16w(reinterpret_cast<const bf16_t *>(abase + (r * lda_b + (unsigned)a_col[t])), slot + j * 512);
                     glds16w(reinterpret_cast<const bf16_t *>(bbase + (r * ldb_b + (unsigned)b_col[t])),
@@ -190,13 +194,17 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
                 for (int nf = 0; nf < 4; ++nf) wf[nf] = tr8(lb, wb[nf] + ks * 32 * WT * 2);
 #pragma unroll
                 for (int mf = 0; mf < 8; ++mf) xf[mf] = tr8(lb, xb[mf] + ks * 32 * WT * 2);
+#ifndef WG_NO_SETPRIO
                 __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
                     for (int mf = 0; mf < 8; ++mf)
                         acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+#ifndef WG_NO_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
+#endif
             }
 #endif
         }

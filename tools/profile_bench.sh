@@ -5,8 +5,8 @@
 set -e
 TAG=$1; R=$PWD; OUT=$R/gpurun_out/prof_$TAG
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG --output-format csv -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT.trace.log 2>&1
+B="python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-train"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG --output-format csv -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-train > $OUT.trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o $TAG --output-format csv -- $B > $OUT.pmc1.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_write -o $TAG --output-format csv -- $B > $OUT.pmc2.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o $TAG --output-format csv -- $B > $OUT.pmc3.log 2>&1
