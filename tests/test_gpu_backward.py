@@ -55,6 +55,9 @@ def _run_both(kind, M, I, E, shape, cf, noisy, seed=11, aux_coef=0.3):
     ("qwen_bias", 64, 64, 2, (1, 70), 1.5),
     ("phi", 128, 256, 4, (2, 130), 1.5),
     ("phi", 64, 576, 8, (1, 257), 1.0),
+    # several 256-wide tiles in every GEMM of the step (weight gradients: 2 x 3 and 6 x 2 tiles per expert)
+    ("stablelm", 512, 768, 4, (2, 333), 1.5),
+    ("phi", 320, 1024, 2, (1, 700), 1.0),
 ])
 @pytest.mark.parametrize("noisy", [False, True])
 def test_block_gradients_vs_oracle_autograd(kind, M, I, E, shape, cf, noisy):
