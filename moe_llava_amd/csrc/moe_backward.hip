@@ -4,7 +4,8 @@
 //   routing backward      dweight, d l_aux -> dlogits through renormalisation, capacity mask and softmax (top2gating)
 //   gate backward         dwg = dlogits^T @ float(x)                                              (F.linear backward)
 //   dispatch backward     dx[s] = sum_j dXrows[pos(s,j)] + dlogits[s] @ wg                         (einsum "sec,sm->ecm")
-//   activation fwd / bwd  over the compact rows (training keeps the pre-activation fc1 output)
+//   activation forward    over the compact rows (training keeps the pre-activation fc1 output; the activation
+//                         BACKWARD is fused into the store phase of the fc2 data-gradient GEMM, moe_gemm.hip)
 //   weight transposes     K-contiguous W^T for the data-gradient launches of the grouped NT GEMM (the weight
 //                         gradients read their operands untransposed: moe_wgrad.hip)
 //   bias gradient         per-expert column sums
@@ -49,54 +50,6 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t *__restrict__
             out = pack8(o);
         }
         *reinterpret_cast<uint4 *>(h + r * I + c * 8) = out;
-    }
-}
-
-// autograd of the bf16 graph: h = silu(a) * b  ->  db = g * silu(a), d silu = g * b, da = d silu * silu'(a)
-// (each product rounded to bf16 as the bf16 tensors of the reference's backward are)
-template <int ACT>
-__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t *__restrict__ ab, const bf16_t *__restrict__ dh,
-                                                      const int *__restrict__ n_rows_dev, int max_rows, int I, int n_gated,
-                                                      bf16_t *__restrict__ dab) {
-    int n = *n_rows_dev;
-    if (n > max_rows) n = max_rows;
-    const int chunks = I >> 3;
-    const long long total = (long long)n * chunks;
-    const int N1 = (ACT == MOE_ACT_SWIGLU) ? 2 * I : I;
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-        const long long r = t / chunks;
-        const int c = (int)(t - r * chunks);
-        const bf16_t *row = ab + r * N1 + c * 8;
-        float a[8], g[8];
-        unpack8(*reinterpret_cast<const uint4 *>(row), a);
-        unpack8(*reinterpret_cast<const uint4 *>(dh + r * I + c * 8), g);
-        if (ACT == MOE_ACT_SWIGLU) {
-            float b[8], da[8], db[8];
-            unpack8(*reinterpret_cast<const uint4 *>(row + I), b);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool gated = c * 8 + i < n_gated;  // RePaMLP: masked channels are 1 * b, no gradient to a
-                const float sig = fast_sigmoid(a[i]);
-                const float sg = gated ? rbf(a[i] * sig) : 1.0f;
-                db[i] = g[i] * sg;
-                const float dsg = rbf(g[i] * b[i]);
-                da[i] = gated ? dsg * (sig * (1.f + a[i] * (1.f - sig))) : 0.f;
-            }
-            *reinterpret_cast<uint4 *>(dab + r * N1 + c * 8) = pack8(da);
-            *reinterpret_cast<uint4 *>(dab + r * N1 + I + c * 8) = pack8(db);
-        } else {
-            float dx[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float x = a[i];
-                const float k = 0.7978845608028654f;
-                const float u = k * (x + 0.044715f * x * x * x);
-                const float th = fast_tanh(u);
-                const float d = 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k * (1.f + 3.f * 0.044715f * x * x);
-                dx[i] = g[i] * d;
-            }
-            *reinterpret_cast<uint4 *>(dab + r * N1 + c * 8) = pack8(dx);
-        }
     }
 }
 
@@ -460,19 +413,6 @@ int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_row
         hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_GELU_NEW>), dim3(grid), dim3(256), 0, st, ab, n_rows_dev, max_rows, I, n_gated,
                            h);
     return check_launch("act_fwd_kernel");
-}
-
-int launch_act_bwd(int act, const bf16_t *ab, const bf16_t *dh, const int *n_rows_dev, int max_rows, int I, int n_gated,
-                   bf16_t *dab, hipStream_t st) {
-    if (n_gated < 0 || n_gated > I) n_gated = I;
-    const int grid = ew_grid((long long)max_rows * (I >> 3));
-    if (act == MOE_ACT_SWIGLU)
-        hipLaunchKernelGGL((act_bwd_kernel<MOE_ACT_SWIGLU>), dim3(grid), dim3(256), 0, st, ab, dh, n_rows_dev, max_rows, I, n_gated,
-                           dab);
-    else
-        hipLaunchKernelGGL((act_bwd_kernel<MOE_ACT_GELU_NEW>), dim3(grid), dim3(256), 0, st, ab, dh, n_rows_dev, max_rows, I,
-                           n_gated, dab);
-    return check_launch("act_bwd_kernel");
 }
 
 int launch_bias_grad(const bf16_t *d, const int *group_offsets, int G, int El, int max_rows, int N, float *out,

@@ -83,6 +83,33 @@ __device__ __forceinline__ float gelu_new_bf16(float x) {
     return rbf(t6 * t5);
 }
 
+// Backward of the activations on 8 packed elements, with the bf16 rounding points of the autograd graph of the
+// reference's bf16 modules.  SwiGLU: h = silu(a) * b (masked channels: h = b):  db = g * silu(a), d silu = g * b,
+// da = d silu * silu'(a).  gelu_new: dx = g * d/dx[0.5 x (1 + tanh(k (x + 0.044715 x^3)))].
+__device__ __forceinline__ void swiglu_bwd8(const float *a, const float *b, const float *g, int c0, int n_gated, float *da,
+                                            float *db) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool gated = c0 + i < n_gated;  // RePaMLP: masked channels are 1 * b, no gradient to a
+        const float sig = fast_sigmoid(a[i]);
+        const float sg = gated ? rbf(a[i] * sig) : 1.0f;
+        db[i] = g[i] * sg;
+        const float dsg = rbf(g[i] * b[i]);
+        da[i] = gated ? dsg * (sig * (1.f + a[i] * (1.f - sig))) : 0.f;
+    }
+}
+__device__ __forceinline__ void gelu_new_bwd8(const float *a, const float *g, float *dx) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = a[i];
+        const float k = 0.7978845608028654f;
+        const float u = k * (x + 0.044715f * x * x * x);
+        const float th = fast_tanh(u);
+        const float d = 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k * (1.f + 3.f * 0.044715f * x * x);
+        dx[i] = g[i] * d;
+    }
+}
+
 // ---- helpers of the backward pass implemented in moe_backward.hip, used by moe_expert_ffn_bwd ----
 // dst[b, c, r] = src[b, r, c]
 int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst, hipStream_t st);
@@ -91,8 +118,6 @@ int launch_wgrad_tn(const bf16_t *a, long long lda, const bf16_t *b, long long l
                     int n_experts, int R, int N, bf16_t *out, hipStream_t st);
 int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, int n_gated, bf16_t *h,
                    hipStream_t st);
-int launch_act_bwd(int act, const bf16_t *ab, const bf16_t *dh, const int *n_rows_dev, int max_rows, int I, int n_gated,
-                   bf16_t *dab, hipStream_t st);
 // out[e, n] = sum over the rows of expert e's groups of d[r, n]  (fp32, zeroed here)
 int launch_bias_grad(const bf16_t *d, const int *group_offsets, int G, int n_experts_local, int max_rows, int N, float *out,
                      hipStream_t st);

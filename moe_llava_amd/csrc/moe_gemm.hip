@@ -35,7 +35,12 @@ constexpr int NTHREADS = 512;
 #endif
 constexpr int RS = GEMM_RS;  // row tiles per super-row (L2 reuse of the W panel inside an XCD)
 
-enum { EPI_PLAIN = MOE_EPI_PLAIN, EPI_SWIGLU = MOE_EPI_SWIGLU, EPI_GELU_NEW = MOE_EPI_GELU_NEW };
+enum {
+    EPI_PLAIN = MOE_EPI_PLAIN, EPI_SWIGLU = MOE_EPI_SWIGLU, EPI_GELU_NEW = MOE_EPI_GELU_NEW,
+    // backward only (not in the C ABI): the GEMM result is dH; the store phase reads the kept pre-activations and
+    // writes the activation gradient dAB instead (act_bwd fused into the data-gradient launch of fc2)
+    EPI_DSWIGLU = 3, EPI_DGELU = 4
+};
 
 struct GemmParams {
     const bf16_t *a;
@@ -57,6 +62,8 @@ struct GemmParams {
     int n_gated;       // gated: output columns >= n_gated bypass SiLU (RePaMLP mask); = N_out for plain SwiGLU
     int max_row_tiles;
     int col_tiles;
+    const bf16_t *aux;  // EPI_DSWIGLU / EPI_DGELU: pre-activations AB [rows, ld_aux]
+    long long ld_aux;
 };
 
 __device__ __forceinline__ void glds16(const bf16_t *gsrc, bf16_t *lds_wave_base) {
@@ -375,8 +382,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             if (prow < row_end && ncols_ok > 0) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(lds + r * ROWB + cc * 16);
                 bf16_t *dst = p.out + (long long)prow * p.ldo + col;
-                if (ncols_ok >= 8) *reinterpret_cast<uint4 *>(dst) = v;
-                else *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
+                if (EPI == EPI_DSWIGLU || EPI == EPI_DGELU) {
+                    // v = 8 elements of dH (bf16, as the standalone path stores them); N_out % 8 == 0 here
+                    const bf16_t *abrow = p.aux + (long long)prow * p.ld_aux + col;
+                    float g[8], a[8];
+                    unpack8(v, g);
+                    unpack8(*reinterpret_cast<const uint4 *>(abrow), a);
+                    if (EPI == EPI_DSWIGLU) {
+                        float b[8], da[8], db[8];
+                        unpack8(*reinterpret_cast<const uint4 *>(abrow + p.b_row_offset), b);
+                        swiglu_bwd8(a, b, g, col, p.n_gated, da, db);
+                        *reinterpret_cast<uint4 *>(dst) = pack8(da);
+                        *reinterpret_cast<uint4 *>(dst + p.b_row_offset) = pack8(db);
+                    } else {
+                        float dx[8];
+                        gelu_new_bwd8(a, g, dx);
+                        *reinterpret_cast<uint4 *>(dst) = pack8(dx);
+                    }
+                } else if (ncols_ok >= 8) {
+                    *reinterpret_cast<uint4 *>(dst) = v;
+                } else {
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
+                }
             }
         }
     }
@@ -484,14 +511,12 @@ extern "C" int moe_debug_read_stamps(unsigned long long *host_dst) {
 }
 #endif
 
-extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
-                                    const void *w, const void *bias, const int32_t *group_offsets, int G,
-                                    int n_experts_local, int max_rows, int K, int N, int n_gated, void *out, int64_t ldo,
-                                    void *stream) {
-    if (epilogue != MOE_EPI_PLAIN && epilogue != MOE_EPI_SWIGLU && epilogue != MOE_EPI_GELU_NEW)
-        return fail(MOE_ERR_ARG, "moe_grouped_gemm_fwd: unknown epilogue %d", epilogue);
-    int rc = gemm_args_ok("moe_grouped_gemm_fwd", a, lda, gather_shift, w, group_offsets, G, n_experts_local, max_rows, K, N,
-                          out, ldo);
+// every grouped GEMM launch goes through here; epilogue may also be one of the internal backward epilogues
+static int grouped_gemm_launch(const char *fn, int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
+                               const void *w, const void *bias, const int32_t *group_offsets, int G, int n_experts_local,
+                               int max_rows, int K, int N, int n_gated, void *out, int64_t ldo, const void *aux,
+                               int64_t ld_aux, void *stream) {
+    int rc = gemm_args_ok(fn, a, lda, gather_shift, w, group_offsets, G, n_experts_local, max_rows, K, N, out, ldo);
     if (rc) return rc;
     if (max_rows == 0) return 0;
     GemmParams p;
@@ -510,6 +535,8 @@ extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, co
     p.N_out = N;
     p.b_row_offset = N;
     p.n_gated = (n_gated < 0 || n_gated > N) ? N : n_gated;
+    p.aux = (const bf16_t *)aux;
+    p.ld_aux = ld_aux;
     hipStream_t st = (hipStream_t)stream;
     const TileChoice t = choose_tile(epilogue, max_rows, G, N);
     if (epilogue == MOE_EPI_SWIGLU) {
@@ -519,8 +546,22 @@ extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, co
     }
     p.w_expert_stride = (long long)N * K;
     p.bias_expert_stride = N;
-    if (epilogue == MOE_EPI_GELU_NEW) return launch_gemm<EPI_GELU_NEW>(p, max_rows, t, st);
-    return launch_gemm<EPI_PLAIN>(p, max_rows, t, st);
+    switch (epilogue) {
+        case MOE_EPI_GELU_NEW: return launch_gemm<EPI_GELU_NEW>(p, max_rows, t, st);
+        case EPI_DSWIGLU: return launch_gemm<EPI_DSWIGLU>(p, max_rows, t, st);
+        case EPI_DGELU: return launch_gemm<EPI_DGELU>(p, max_rows, t, st);
+        default: return launch_gemm<EPI_PLAIN>(p, max_rows, t, st);
+    }
+}
+
+extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
+                                    const void *w, const void *bias, const int32_t *group_offsets, int G,
+                                    int n_experts_local, int max_rows, int K, int N, int n_gated, void *out, int64_t ldo,
+                                    void *stream) {
+    if (epilogue != MOE_EPI_PLAIN && epilogue != MOE_EPI_SWIGLU && epilogue != MOE_EPI_GELU_NEW)
+        return fail(MOE_ERR_ARG, "moe_grouped_gemm_fwd: unknown epilogue %d", epilogue);
+    return grouped_gemm_launch("moe_grouped_gemm_fwd", epilogue, a, lda, gather, gather_shift, w, bias, group_offsets, G,
+                               n_experts_local, max_rows, K, N, n_gated, out, ldo, nullptr, 0, stream);
 }
 
 extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
@@ -567,7 +608,7 @@ extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, con
 
 namespace {
 struct BwdWs {
-    bf16_t *wt, *dh, *dab, *xr;
+    bf16_t *wt, *dab, *xr;
     size_t total;
 };
 inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -582,7 +623,6 @@ BwdWs carve_bwd(void *ws, int act, int G, int El, int max_rows, int M, int I) {
         return ptr;
     };
     r.wt = (bf16_t *)take(2 * (size_t)El * M * N1);        // W2^T, then W1^T
-    r.dh = (bf16_t *)take(2 * (size_t)max_rows * I);
     r.dab = (bf16_t *)take(2 * (size_t)max_rows * N1);
     r.xr = (bf16_t *)take(2 * (size_t)max_rows * M);       // gathered input rows (only when a gather index is given)
     r.total = off;
@@ -620,16 +660,13 @@ extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int
     int rc;
     // ---- fc2: dH = dY @ W2, dW2 = dY^T @ H, db2 = colsum(dY) ----
     if ((rc = launch_transpose_batched((const bf16_t *)w2, El, M, I, ws.wt, st))) return rc;  // W2^T [El, I, M]
-    if ((rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, dy, M, nullptr, 0, ws.wt, nullptr, group_offsets, G, El, max_rows, M, I,
-                                   -1, ws.dh, I, stream)))
+    // dH = dY @ W2 never reaches HBM: the store phase of this launch turns each dH chunk into dAB with the kept
+    // pre-activations (same arithmetic and rounding as act_bwd_kernel on a bf16 dH)
+    if ((rc = grouped_gemm_launch(fn, act == MOE_ACT_SWIGLU ? EPI_DSWIGLU : EPI_DGELU, dy, M, nullptr, 0, ws.wt, nullptr,
+                                  group_offsets, G, El, max_rows, M, I, n_gated, ws.dab, N1, ab, N1, stream)))
         return rc;
-    if ((rc = launch_wgrad_tn(dyp, M, (const bf16_t *)h, I, group_offsets, G, El, M, I, (bf16_t *)dw2, st)))
-        return rc;
+    if ((rc = launch_wgrad_tn(dyp, M, (const bf16_t *)h, I, group_offsets, G, El, M, I, (bf16_t *)dw2, st))) return rc;
     if (db2 && (rc = launch_bias_grad(dyp, group_offsets, G, El, max_rows, M, db2, st))) return rc;
-    // ---- activation ----
-    if (max_rows > 0 &&
-        (rc = launch_act_bwd(act, (const bf16_t *)ab, ws.dh, group_offsets + G, max_rows, I, n_gated, ws.dab, st)))
-        return rc;
     // ---- fc1: dA = dAB @ W1, dW1 = dAB^T @ A, db1 = colsum(dAB) ----
     if ((rc = launch_transpose_batched((const bf16_t *)w1, El, N1, M, ws.wt, st))) return rc;  // W1^T [El, M, N1]
     if ((rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, ws.dab, N1, nullptr, 0, ws.wt, nullptr, group_offsets, G, El, max_rows, N1,
