@@ -185,7 +185,8 @@ def main():
     if ep == 1:
         rows_local = int(r.expert_offsets[-1])               # kept (token, expert) pairs = GEMM rows this launch
     else:
-        rows_local = moe.deepspeed_moe.last_ffn_rows         # rows received by this rank's experts (last step)
+        # rows received by this rank's experts per grouped-FFN launch (the exchange is pipelined in chunks)
+        rows_local = moe.deepspeed_moe.last_ffn_rows // max(1, moe.deepspeed_moe.last_ffn_launches)
     fc1_avg = statistics.mean(fc1_ms) if fc1_ms else None
     roofline = None
     if fc1_avg and rows_local is not None:

@@ -142,6 +142,16 @@ def _all_to_all_rows(out: Tensor, inp: Tensor, out_splits, in_splits, group) -> 
     dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
 
 
+def _all_to_all_rows_async(out: Tensor, inp: Tensor, out_splits, in_splits, group):
+    """Like ``_all_to_all_rows`` but returns a work handle (None when it already completed): with RCCL the
+    exchange runs on the communicator's stream, so kernels launched meanwhile on the compute stream overlap it."""
+    import torch.distributed as dist
+    if inp.is_cuda and _group_is_gloo(group):
+        _all_to_all_rows(out, inp, out_splits, in_splits, group)
+        return None
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=True)
+
+
 def _all_gather_counts(local: Tensor, ep: int, group) -> Tensor:
     """[ep, E] int32 matrix of every EP rank's kept counts, on the host."""
     import torch.distributed as dist
@@ -176,6 +186,10 @@ class MOELayer(nn.Module):
         self.last_ffn_rows: Optional[int] = None
         #: set to an ops.PhaseTimer to record HIP events around gate / fc1 / fc2 / combine (wall_clock_breakdown)
         self.timer: Optional[ops.PhaseTimer] = None
+        #: grouped-FFN launches the last expert-parallel forward was split into (chunks of the exchange)
+        self.last_ffn_launches: int = 1
+        #: run the exchange path even when ep_size == 1 (single-rank group; exercises the RCCL code on one GPU)
+        self.force_exchange: bool = False
 
     def _set_ep_group(self, ep_group):
         self.ep_group = ep_group
@@ -217,7 +231,7 @@ class MOELayer(nn.Module):
         ng = self.experts.n_gated
         shift = r.top_k - 1                      # perm holds token * top_k + choice
         saved = None
-        if self.ep_size == 1:
+        if self.ep_size == 1 and not (self.force_exchange and self.ep_group is not None):
             if save:
                 y, ab, h = ops.expert_ffn_train(act, x, r.perm, shift, w1, b1, w2, b2, r.expert_offsets, r.max_rows, ng)
                 saved = dict(a=x, gather=r.perm, shift=shift, ab=ab, h=h, offs=r.expert_offsets, rows=r.max_rows)
@@ -239,7 +253,7 @@ class MOELayer(nn.Module):
         x, r = saved["x"], saved["r"]
         S, M = x.shape
         dy, dweight = ops.combine_bwd(dout, saved["y"], r, S, M)
-        if self.ep_size == 1:
+        if "gather" in saved:                    # local path (no exchange in the forward pass)
             da_rows, dw1, db1, dw2, db2 = ops.expert_ffn_bwd(
                 saved["act"], saved["a"], saved["gather"], saved["shift"], saved["w1"], saved["w2"], saved["ab"],
                 saved["h"], dy, saved["offs"], saved["rows"], saved["has_b1"], saved["has_b2"], saved["ng"])
@@ -279,6 +293,10 @@ class MOELayer(nn.Module):
         recv_splits = recv_mat.sum(1).tolist()
         n_send, n_recv = int(sum(send_splits)), int(sum(recv_splits))
         self.last_ffn_rows = n_recv
+        self.last_ffn_launches = 1
+        chunks = _ep_chunks(n_send, n_recv)
+        if not save and chunks > 1:
+            return self._expert_parallel_chunked(x, r, act, w1, b1, w2, b2, kept_h, me, chunks), None
         send = ops.gather_rows(x, r.perm, r.top_k - 1, r.expert_offsets[E:E + 1], n_send)
         recv = torch.empty((max(n_recv, 1), M), dtype=torch.bfloat16, device=x.device)
         _all_to_all_rows(recv[:n_recv], send[:n_send], recv_splits, send_splits, self.ep_group)
@@ -297,6 +315,80 @@ class MOELayer(nn.Module):
         y = torch.empty((max(n_send, r.max_rows, 1), M), dtype=torch.bfloat16, device=x.device)
         _all_to_all_rows(y[:n_send], y_recv[:n_recv], send_splits, recv_splits, self.ep_group)
         return y, saved
+
+
+def _ep_chunks(n_send: int, n_recv: int) -> int:
+    """Chunks the expert-parallel exchange is pipelined in (MOE_EP_CHUNKS overrides; 1 = one exchange each way)."""
+    import os
+    env = os.environ.get("MOE_EP_CHUNKS")
+    if env:
+        return max(1, int(env))
+    return 4 if min(n_send, n_recv) >= 16384 else 1
+
+
+def _expert_parallel_chunked(self, x, r, act, w1, b1, w2, b2, kept_h, me, C):
+    """Forward-only exchange in C chunks so that the all-to-all of chunk c+1 (and the return of chunk c-1) run on
+    RCCL's stream while the grouped FFN of chunk c runs on the compute stream.  xGMI gives one ~50-60 GB/s link per
+    peer, so at the bench's shapes an unpipelined exchange costs about as much as the FFN itself.
+
+    Chunk c takes rows [c*k/C, (c+1)*k/C) of every (source rank, expert) pair's k kept rows, so both sides derive
+    every split size from the one [ep, E] count matrix.  The send buffer is built chunk-major in one gather launch
+    (through a reordered copy of the dispatch index); the returned rows are put back in compact order by one more."""
+    ep, El = self.ep_size, self.num_local_experts
+    E = ep * El
+    M = x.shape[1]
+    dev = x.device
+    k = kept_h.numpy().astype(np.int64)                                  # [src, e]
+    edges = (k[:, :, None] * np.arange(C + 1, dtype=np.int64)) // C      # [src, e, C+1]
+    cnt = edges[:, :, 1:] - edges[:, :, :-1]                             # [src, e, c]
+    my_off = np.concatenate([[0], np.cumsum(k[me])])                     # compact offsets of my rows per expert
+    order = np.concatenate([np.arange(my_off[e] + edges[me, e, c], my_off[e] + edges[me, e, c + 1])
+                            for c in range(C) for e in range(E)] + [np.zeros(0, dtype=np.int64)])
+    n_send = int(order.size)
+    inv = np.empty(max(n_send, 1), dtype=np.int32)
+    inv[order] = np.arange(n_send, dtype=np.int32)
+    order_d = torch.from_numpy(order.astype(np.int64)).to(dev, non_blocking=True)
+    inv_d = torch.from_numpy(inv).to(dev, non_blocking=True)
+    send_cnt = cnt[me].reshape(ep, El, C).sum(1)                         # [dest, c]
+    recv_cnt = cnt[:, me * El:(me + 1) * El, :]                          # [src, le, c]
+    n_total_dev = r.expert_offsets[E:E + 1]
+    perm_c = r.perm[:n_send][order_d] if n_send else r.perm[:0]          # dispatch index in chunk-major order
+    send = ops.gather_rows(x, perm_c.contiguous(), r.top_k - 1, n_total_dev, n_send)
+    # all chunks' group offsets in one host->device copy: [C, ep*El + 1]
+    offs_h = np.zeros((C, ep * El + 1), dtype=np.int32)
+    offs_h[:, 1:] = np.cumsum(recv_cnt.reshape(ep * El, C).T, axis=1)
+    offs_d = torch.from_numpy(offs_h).to(dev, non_blocking=True)
+    send_edges = np.concatenate([[0], np.cumsum(send_cnt.sum(0))])       # chunk boundaries in the send buffer
+    recvs, works = [], []
+    for c in range(C):
+        n_rc = int(offs_h[c, -1])
+        rc = torch.empty((max(n_rc, 1), M), dtype=torch.bfloat16, device=dev)
+        w = _all_to_all_rows_async(rc[:n_rc], send[send_edges[c]:send_edges[c + 1]], recv_cnt[:, :, c].sum(1).tolist(),
+                                   send_cnt[:, c].tolist(), self.ep_group)
+        recvs.append((rc, n_rc))
+        works.append(w)
+    y_cm = torch.empty((max(n_send, 1), M), dtype=torch.bfloat16, device=dev)   # returned rows, chunk-major
+    back, keep = [], []
+    for c in range(C):
+        if works[c] is not None:
+            works[c].wait()
+        rc, n_rc = recvs[c]
+        y_rc = ops.expert_ffn(act, rc, None, 0, w1, b1, w2, b2, offs_d[c], n_rc, timer=self.timer,
+                              n_gated=self.experts.n_gated)
+        keep.append(y_rc)
+        back.append(_all_to_all_rows_async(y_cm[send_edges[c]:send_edges[c + 1]], y_rc[:n_rc], send_cnt[:, c].tolist(),
+                                           recv_cnt[:, :, c].sum(1).tolist(), self.ep_group))
+    for w in back:
+        if w is not None:
+            w.wait()
+    self.last_ffn_launches = C
+    y = ops.gather_rows(y_cm, inv_d, 0, n_total_dev, n_send)            # back to compact (expert-major) order
+    if y.shape[0] < max(r.max_rows, 1):
+        y = torch.cat([y, y.new_empty((max(r.max_rows, 1) - y.shape[0], M))], 0)
+    return y
+
+
+MOELayer._expert_parallel_chunked = _expert_parallel_chunked
 
 
 class _MoEBlockFn(torch.autograd.Function):

@@ -196,6 +196,45 @@ def _build(M, I, E, ep, seed, kind):
     return full, part
 
 
+def run_single_rank_rccl(rank: int, port: int, result_dir: str):
+    """The exchange code on the real RCCL backend with a one-rank group (RCCL refuses two ranks on one GPU):
+    asynchronous all_to_all_single on the communicator's stream, chunked pipeline, results equal the local path."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        full, _ = _build(256, 512, 4, 1, seed=8, kind="stablelm")
+        full = full.to(dev).eval()
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(4, 700, 256, generator=g).to(torch.bfloat16).to(dev)
+        with torch.no_grad():
+            want, l_ref, c_ref = full(x)
+            layer = full.deepspeed_moe
+            layer.force_exchange = True
+            layer._set_ep_group(dist.group.WORLD)
+            for chunks in ("1", "4"):
+                os.environ["MOE_EP_CHUNKS"] = chunks
+                got, l_aux, cnt = full(x)
+                torch.cuda.synchronize()
+                assert layer.last_ffn_launches == int(chunks)
+                assert torch.equal(got, want) and torch.equal(cnt, c_ref) and float(l_aux) == float(l_ref)
+        # training step through the exchange path (unchunked) on RCCL
+        del os.environ["MOE_EP_CHUNKS"]
+        full.train()
+        xg = x.clone().requires_grad_(True)
+        o, la, _ = full(xg)
+        (o.float().sum() + la).backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(xg.grad.float()).all()
+        with open(os.path.join(result_dir, "ok_0"), "w") as f:
+            f.write("rccl single rank ok\n")
+    finally:
+        dist.destroy_process_group()
+
+
 def run(rank: int, world: int, port: int, mode: str, kind: str, result_dir: str):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -236,6 +275,20 @@ def run(rank: int, world: int, port: int, mode: str, kind: str, result_dir: str)
             assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
         else:
             assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-3)
+        # ---- pipelined exchange (3 chunks, odd on purpose): same rows, same results ----
+        os.environ["MOE_EP_CHUNKS"] = "3"
+        try:
+            with torch.no_grad():
+                got3, l3, c3 = part(x)
+        finally:
+            del os.environ["MOE_EP_CHUNKS"]
+        assert part.deepspeed_moe.last_ffn_launches == 3
+        assert torch.equal(c3.cpu(), c_ref.cpu()) and float(l3) == float(l_ref)
+        if mode == "gpu":
+            torch.cuda.synchronize()
+            assert torch.equal(got3, want), float((got3.float() - want.float()).abs().max())
+        else:
+            assert torch.allclose(got3.float(), want.float(), rtol=1e-2, atol=1e-3)
         # ---- backward through the exchange: dy rows travel the reverse route ----
         g2 = torch.Generator().manual_seed(300 + rank)
         R = torch.randn(1, S, M, generator=g2).to(torch.bfloat16).to(dev)

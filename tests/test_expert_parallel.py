@@ -40,3 +40,10 @@ def test_expert_parallel_exchange_cpu_gloo(kind):
 def test_expert_parallel_two_ranks_one_gpu(kind):
     info = _spawn("gpu", kind)
     print(info)
+
+
+@pytest.mark.gpu
+def test_exchange_path_on_rccl_single_rank():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(ep_worker.run_single_rank_rccl, args=(_free_port(), d), nprocs=1, join=True)
+        assert os.listdir(d) == ["ok_0"]
