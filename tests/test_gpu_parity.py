@@ -248,21 +248,25 @@ def test_cfg1_block_vs_index_oracle(kind, M, I):
     assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-2 * scale)
 
 
-def test_full_size_properties_cfg2():
-    """BASELINE config 2 size (batch 32 -> S = 22 528): size-independent properties instead of a full CPU run."""
+def _full_size_check(kind, M, I, E, B, T, cf, stress=False):
+    """Size-independent properties at a BASELINE shape instead of a full CPU run: determinism, counts, capacity,
+    perm = inverse of (expert, slot), routing equal to the index oracle given the kernel's logits, rows that lost
+    both choices exactly zero, and a sample of output rows against the oracle expert MLPs."""
     import moe_llava_amd
-    from moe_llava_amd.expert_mlps import StableLMMLP
-    M, I, E, B, T = 2048, 5632, 4, 32, 704
+    from moe_llava_amd.expert_mlps import PhiMLP, QWenMLP, StableLMMLP
+    mk = {"stablelm": (StableLMMLP, StableLMMLPRef), "phi": (PhiMLP, PhiMLPRef), "qwen": (QWenMLP, QWenMLPRef)}[kind]
     torch.manual_seed(0)
-    moe = moe_llava_amd.MoE(M, StableLMMLP(M, I), num_experts=E, k=2, capacity_factor=1.5,
+    moe = moe_llava_amd.MoE(M, mk[0](M, I), num_experts=E, k=2, capacity_factor=cf,
                             eval_capacity_factor=2.0, min_capacity=0, top2_2nd_expert_sampling=False)
     moe = moe.to(torch.bfloat16)
     for p in moe.deepspeed_moe.experts.parameters():
         p.data.normal_(0, 0.02)
     moe.deepspeed_moe.gate.wg.weight.data.normal_(0, 0.2)
+    if stress:                                         # SURVEY 8d capacity-drop stress: expert 0 overflows
+        moe.deepspeed_moe.gate.wg.weight.data[0] += 0.05
     moe = moe.to(DEV).train()
     x = torch.randn(B, T, M, device=DEV).to(torch.bfloat16)
-    x[:, :576] += 0.5                                  # "image" rows skew the router (drops happen)
+    x[:, : (T * 4) // 5] += 0.5                        # "image" rows skew the router (drops happen)
     with torch.no_grad():
         out1, l1, c1 = moe(x)
         r = moe.deepspeed_moe.last_routing
@@ -271,8 +275,8 @@ def test_full_size_properties_cfg2():
     S = B * T
     assert torch.equal(out1, out2) and torch.equal(c1, c2) and float(l1) == float(l2)        # deterministic
     assert int(c1.sum()) == 2 * S
-    C = lit.capacity_of(S, E, 3.0, 0)
-    assert r.capacity == C == 16896
+    C = lit.capacity_of(S, E, cf * 2, 0)
+    assert r.capacity == C
     kept = r.kept_counts.cpu()
     assert int(kept.max()) <= C
     offs = r.expert_offsets.cpu()
@@ -293,17 +297,41 @@ def test_full_size_properties_cfg2():
     o = out1.reshape(-1, M)
     if dead.any():
         assert float(o[dead.to(DEV)].float().abs().max()) == 0.0
+    if stress:
+        assert int((slot < 0).sum()) > 0                                # the stress really drops
     # sampled rows against the oracle MLPs
     sample = torch.randperm(S, generator=torch.Generator().manual_seed(1))[:48]
     sub = {k: (v[sample] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == S else v) for k, v in ref.items()}
-    cpu_experts = [StableLMMLPRef(M, I).to(torch.bfloat16) for _ in range(E)]
+    cpu_experts = [mk[1](M, I).to(torch.bfloat16) for _ in range(E)]
     for ce, ge in zip(cpu_experts, moe.deepspeed_moe.experts.deepspeed_experts):
         ce.load_state_dict({k: v.cpu() for k, v in ge.state_dict().items()})
     with torch.no_grad():
         want = ix.moe_forward_index(x.reshape(-1, M)[sample.to(DEV)].cpu(), sub, cpu_experts)
     got = o[sample.to(DEV)].cpu()
-    err, scale = _report("cfg2 sampled rows", got, want)
+    err, scale = _report(f"{kind} M{M} I{I} E{E} S{S} sampled rows", got, want)
     assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-2 * scale)
+    return r
+
+
+def test_full_size_properties_cfg2():
+    """BASELINE config 2: StableLM-1.6B-4e block, batch 32 -> S = 22 528."""
+    r = _full_size_check("stablelm", 2048, 5632, 4, 32, 704, 1.5)
+    assert r.capacity == 16896
+
+
+def test_full_size_properties_cfg3_phi_rank_share():
+    """BASELINE config 3 (Phi2-384: M 2560, I 10 240, gelu_new + biases): one GPU's share at EP = 4, 16 x 857 rows."""
+    _full_size_check("phi", 2560, 10240, 4, 16, 857, 1.5)
+
+
+def test_full_size_properties_cfg4_qwen():
+    """BASELINE config 4 (Qwen-1.8B-4e: I = 5504, not a multiple of 256; 4 x 576 + 128 tokens per sample)."""
+    _full_size_check("qwen", 2048, 5504, 4, 4, 2432, 1.5)
+
+
+def test_full_size_properties_cfg5_drop_stress():
+    """BASELINE config 5 shape per GPU: 8 experts of Phi-2 width, capacity-drop stress (cf 1.0, expert 0 overloaded)."""
+    _full_size_check("phi", 2560, 10240, 8, 32, 1024, 1.0, stress=True)
 
 
 def test_experts_forward_reference_layout():
