@@ -105,12 +105,22 @@ class Experts(nn.Module):
 
     # ---- packed weights ----------------------------------------------------------------------
     def _specs(self) -> List[ExpertSpec]:
+        # The mapping module -> (activation, Linears) is fixed for a module's lifetime (reparam() replaces the
+        # Parameters inside the same nn.Linear objects); only the RePaMLP gated-channel count can change between
+        # calls.  Caching it keeps the per-call host cost low (decode steps are launch-bound).
+        cached = getattr(self, "_spec_cache", None)
+        if cached is not None and len(cached) == len(self.deepspeed_experts):
+            ng = _repa_gated(self.deepspeed_experts[0]) if cached[0].act == ops.ACT_SWIGLU else -1
+            if ng == cached[0].n_gated:
+                self.n_gated = ng
+                return cached
         specs = [describe_expert(e) for e in self.deepspeed_experts]
         a0, n0 = specs[0].act, len(specs[0].fc1)
         for s in specs:
             if s.act != a0 or len(s.fc1) != n0 or s.n_gated != specs[0].n_gated:
                 raise ValueError("all local experts must share one MLP form")
         self.n_gated = specs[0].n_gated
+        self._spec_cache = specs
         return specs
 
     def _params(self, specs) -> List[nn.Parameter]:

@@ -53,6 +53,25 @@ def _stream_ptr(t: Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _on(dev: torch.device):
+    """Context that makes ``dev`` the current HIP device; free when it already is (the common case: at decode sizes
+    the host-side cost of a call is comparable to its GPU time)."""
+    if dev.type == "cuda" and torch.cuda.current_device() == (dev.index if dev.index is not None else 0):
+        return _NULL
+    return torch.cuda.device(dev)
+
+
 def _need(t: Tensor, name: str, dtype, ndim: Optional[int] = None) -> None:
     if not isinstance(t, Tensor):
         raise TypeError(f"{name}: expected a tensor")
@@ -98,7 +117,7 @@ def gate_logits(x: Tensor, wg_weight: Tensor) -> Tensor:
         raise ValueError(f"wg.weight {tuple(wg_weight.shape)} on {wg_weight.device} does not match x {tuple(x.shape)} on {x.device}")
     logits = torch.empty((S, E), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.moe_gate_logits_fwd(x.data_ptr(), wg_weight.data_ptr(), int(wg_weight.dtype == torch.bfloat16),
                                      logits.data_ptr(), S, M, E, _stream_ptr(x))
     _lib.check(rc, "moe_gate_logits_fwd")
@@ -131,7 +150,7 @@ def routing_top2(logits: Tensor, capacity: int, noise: Optional[Tensor] = None,
     lib = _lib.load()
     ws_bytes = lib.moe_routing_workspace_bytes(S, E)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.moe_routing_top2_fwd(logits.data_ptr(), noise.data_ptr() if noise is not None else None,
                                       int(noise_seed) & 0xFFFFFFFFFFFFFFFF, S, E, int(capacity), int(bool(drop_tokens)),
                                       expert_idx.data_ptr(), slot.data_ptr(), weight.data_ptr(),
@@ -174,7 +193,7 @@ def routing_top1(logits: Tensor, capacity: int, used_token: Optional[Tensor] = N
     lib = _lib.load()
     ws_bytes = lib.moe_routing_top1_workspace_bytes(S, E)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.moe_routing_top1_fwd(
             logits.data_ptr(), noise.data_ptr() if noise is not None else None, int(noise_seed) & 0xFFFFFFFFFFFFFFFF,
             ut.data_ptr() if ut is not None else None, rts_uniform.data_ptr() if rts_uniform is not None else None,
@@ -226,7 +245,7 @@ def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
     gp = gather.data_ptr() if gather is not None else None
     b1p = b1.data_ptr() if b1 is not None else None
     b2p = b2.data_ptr() if b2 is not None else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         if timer is None:
             rc = lib.moe_expert_ffn_fwd(act, a.data_ptr(), a.stride(0), gp, gather_shift, w1.data_ptr(), b1p,
                                         w2.data_ptr(), b2p, group_offsets.data_ptr(), G, n_local, max_rows, M, I,
@@ -258,7 +277,7 @@ def gather_rows(src: Tensor, gather: Tensor, gather_shift: int, n_rows_dev: Tens
         raise ValueError("gather shorter than max_rows")
     dst = torch.empty((max(max_rows, 1), src.shape[1]), dtype=torch.bfloat16, device=src.device)
     lib = _lib.load()
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         rc = lib.moe_gather_rows_fwd(src.data_ptr(), gather.data_ptr(), gather_shift, n_rows_dev.data_ptr(),
                                      max_rows, src.shape[1], dst.data_ptr(), _stream_ptr(src))
     _lib.check(rc, "moe_gather_rows_fwd")
@@ -274,7 +293,7 @@ def combine(y: Tensor, r: Routing, S: int, M: int) -> Tensor:
         raise ValueError("routing does not match S")
     out = torch.empty((S, M), dtype=torch.bfloat16, device=y.device)
     lib = _lib.load()
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         rc = lib.moe_combine_fwd(y.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(), r.weight.data_ptr(),
                                  r.expert_offsets.data_ptr(), S, M, r.expert_idx.shape[1], out.data_ptr(),
                                  _stream_ptr(y))
@@ -318,7 +337,7 @@ def expert_ffn_train(act: int, a: Tensor, gather: Optional[Tensor], gather_shift
     if max_rows == 0:
         return y, ab, h
     lib = _lib.load()
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.moe_expert_ffn_fwd_train(
             act, a.data_ptr(), a.stride(0), gather.data_ptr() if gather is not None else None, gather_shift,
             w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
@@ -354,7 +373,7 @@ def expert_ffn_bwd(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: 
     lib = _lib.load()
     nws = lib.moe_expert_ffn_bwd_workspace_bytes(act, G, n_local, max_rows, M, I)
     ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.moe_expert_ffn_bwd(
             act, a.data_ptr(), a.stride(0), gather.data_ptr() if gather is not None else None, gather_shift,
             w1.data_ptr(), w2.data_ptr(), ab.data_ptr(), h.data_ptr(), dy.data_ptr(), group_offsets.data_ptr(), G,
@@ -374,7 +393,7 @@ def combine_bwd(dout: Tensor, y: Tensor, r: Routing, S: int, M: int):
     k = r.expert_idx.shape[1]
     dweight = torch.empty((S, k), dtype=torch.float32, device=y.device)
     lib = _lib.load()
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         rc = lib.moe_combine_bwd(dout.data_ptr(), y.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(),
                                  r.weight.data_ptr(), r.expert_offsets.data_ptr(), S, M, k, dy.data_ptr(),
                                  dweight.data_ptr(), _stream_ptr(y))
@@ -396,7 +415,7 @@ def gate_bwd(x: Tensor, logits: Tensor, r: Routing, dweight: Tensor, dl_aux: Opt
     lib = _lib.load()
     nws = lib.moe_gate_bwd_workspace_bytes(S, M, E)
     ws = torch.empty((nws,), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.moe_gate_bwd(x.data_ptr(), logits.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(),
                               dweight.data_ptr(), dl_aux.data_ptr() if dl_aux is not None else None,
                               r.used_token.data_ptr() if r.used_token is not None else None, S, M, E, r.top_k,
@@ -412,7 +431,7 @@ def dispatch_bwd(da_rows: Tensor, r: Routing, dlogits: Optional[Tensor], wg_weig
     E = r.exp_counts.numel()
     dx = torch.empty((S, M), dtype=torch.bfloat16, device=da_rows.device)
     lib = _lib.load()
-    with torch.cuda.device(da_rows.device):
+    with _on(da_rows.device):
         rc = lib.moe_dispatch_bwd(da_rows.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(),
                                   r.expert_offsets.data_ptr(),
                                   dlogits.data_ptr() if dlogits is not None else None,
