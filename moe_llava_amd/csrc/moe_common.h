@@ -110,6 +110,41 @@ __device__ __forceinline__ void gelu_new_bwd8(const float *a, const float *g, fl
     }
 }
 
+enum {
+    EPI_PLAIN = MOE_EPI_PLAIN, EPI_SWIGLU = MOE_EPI_SWIGLU, EPI_GELU_NEW = MOE_EPI_GELU_NEW,
+    // backward only (not in the C ABI): the GEMM result is dH; the store phase reads the kept pre-activations and
+    // writes the activation gradient dAB instead (act_bwd fused into the data-gradient launch of fc2)
+    EPI_DSWIGLU = 3, EPI_DGELU = 4
+};
+
+struct GemmParams {
+    const bf16_t *a;
+    long long lda;
+    const int *gather;
+    int gather_shift;
+    const bf16_t *w;
+    long long w_expert_stride;
+    const bf16_t *bias;
+    long long bias_expert_stride;
+    const int *group_offsets;
+    int G;
+    int n_experts;
+    bf16_t *out;
+    long long ldo;
+    int K;
+    int N_out;         // output columns
+    int b_row_offset;  // gated: W row of the first 'b' projection row (= I)
+    int n_gated;       // gated: output columns >= n_gated bypass SiLU (RePaMLP mask); = N_out for plain SwiGLU
+    int max_row_tiles;
+    int col_tiles;
+    const bf16_t *aux;  // EPI_DSWIGLU / EPI_DGELU: pre-activations AB [rows, ld_aux]
+    long long ld_aux;
+};
+
+// Decode-size launches (moe_gemv.hip): every group has at most SKINNY_MAX_ROWS rows.
+constexpr int SKINNY_MAX_ROWS = 64;
+int launch_skinny_gemm(const GemmParams &p, int epilogue, hipStream_t st);
+
 // ---- helpers of the backward pass implemented in moe_backward.hip, used by moe_expert_ffn_bwd ----
 // dst[b, c, r] = src[b, r, c]
 int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst, hipStream_t st);

@@ -35,37 +35,6 @@ constexpr int NTHREADS = 512;
 #endif
 constexpr int RS = GEMM_RS;  // row tiles per super-row (L2 reuse of the W panel inside an XCD)
 
-enum {
-    EPI_PLAIN = MOE_EPI_PLAIN, EPI_SWIGLU = MOE_EPI_SWIGLU, EPI_GELU_NEW = MOE_EPI_GELU_NEW,
-    // backward only (not in the C ABI): the GEMM result is dH; the store phase reads the kept pre-activations and
-    // writes the activation gradient dAB instead (act_bwd fused into the data-gradient launch of fc2)
-    EPI_DSWIGLU = 3, EPI_DGELU = 4
-};
-
-struct GemmParams {
-    const bf16_t *a;
-    long long lda;
-    const int *gather;
-    int gather_shift;
-    const bf16_t *w;
-    long long w_expert_stride;
-    const bf16_t *bias;
-    long long bias_expert_stride;
-    const int *group_offsets;
-    int G;
-    int n_experts;
-    bf16_t *out;
-    long long ldo;
-    int K;
-    int N_out;         // output columns
-    int b_row_offset;  // gated: W row of the first 'b' projection row (= I)
-    int n_gated;       // gated: output columns >= n_gated bypass SiLU (RePaMLP mask); = N_out for plain SwiGLU
-    int max_row_tiles;
-    int col_tiles;
-    const bf16_t *aux;  // EPI_DSWIGLU / EPI_DGELU: pre-activations AB [rows, ld_aux]
-    long long ld_aux;
-};
-
 __device__ __forceinline__ void glds16(const bf16_t *gsrc, bf16_t *lds_wave_base) {
     __builtin_amdgcn_global_load_lds(
         reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(gsrc)),
@@ -538,14 +507,13 @@ static int grouped_gemm_launch(const char *fn, int epilogue, const void *a, int6
     p.aux = (const bf16_t *)aux;
     p.ld_aux = ld_aux;
     hipStream_t st = (hipStream_t)stream;
+    p.w_expert_stride = (epilogue == MOE_EPI_SWIGLU ? 2ll : 1ll) * N * K;
+    p.bias_expert_stride = (epilogue == MOE_EPI_SWIGLU ? 2ll : 1ll) * N;
+    // decode steps (at most 64 compact rows in the whole launch): weight-streaming GEMV-style kernel, no LDS tiles
+    if (max_rows <= SKINNY_MAX_ROWS && epilogue <= MOE_EPI_GELU_NEW && !getenv("MOE_NO_SKINNY"))
+        return launch_skinny_gemm(p, epilogue, st);
     const TileChoice t = choose_tile(epilogue, max_rows, G, N);
-    if (epilogue == MOE_EPI_SWIGLU) {
-        p.w_expert_stride = 2ll * N * K;
-        p.bias_expert_stride = 2ll * N;
-        return launch_gemm<EPI_SWIGLU>(p, max_rows, t, st);
-    }
-    p.w_expert_stride = (long long)N * K;
-    p.bias_expert_stride = N;
+    if (epilogue == MOE_EPI_SWIGLU) return launch_gemm<EPI_SWIGLU>(p, max_rows, t, st);
     switch (epilogue) {
         case MOE_EPI_GELU_NEW: return launch_gemm<EPI_GELU_NEW>(p, max_rows, t, st);
         case EPI_DSWIGLU: return launch_gemm<EPI_DSWIGLU>(p, max_rows, t, st);

@@ -452,3 +452,28 @@ def test_fused_and_three_kernel_routing_agree():
         C = lit.capacity_of(S, E, 2.0, 0)
         _check_routing(big[:S].contiguous(), C)
     _check_routing(big[:4097].contiguous(), lit.capacity_of(4097, E, 2.0, 0))
+
+
+@pytest.mark.parametrize("kind,M,I,E", [("stablelm", 256, 384, 4), ("phi", 128, 512, 4), ("qwen_bias", 64, 192, 8)])
+@pytest.mark.parametrize("S", [1, 2, 5, 17, 32])
+def test_decode_sizes_skinny_kernel_vs_oracle_and_tiled(kind, M, I, E, S):
+    """Decode steps (<= 64 compact rows) run the weight-streaming GEMV-style kernel: outputs match the oracle to the
+    usual bar and the tiled kernel to bf16 rounding (the K split changes the fp32 summation order)."""
+    import os
+    ref, mine, x = _build_pair(kind, M, I, E, (S, 1), 1.0, seed=31, training=False)
+    with torch.no_grad():
+        out, l_aux, cnt = mine(x.to(DEV))
+        os.environ["MOE_NO_SKINNY"] = "1"
+        try:
+            out_tiled, _, _ = mine(x.to(DEV))
+        finally:
+            del os.environ["MOE_NO_SKINNY"]
+    torch.cuda.synchronize()
+    assert mine.deepspeed_moe.last_routing.max_rows <= 64
+    ref.deepspeed_moe.gate.logits_override = mine.deepspeed_moe.gate.last_logits.cpu()
+    with torch.no_grad():
+        r_out, r_laux, r_cnt = ref(x)
+    assert torch.equal(cnt.cpu(), r_cnt)
+    err, scale = _report(f"decode {kind} S{S}", out.cpu(), r_out)
+    assert torch.allclose(out.cpu().float(), r_out.float(), rtol=1e-2, atol=1e-2 * scale)
+    assert torch.allclose(out.float(), out_tiled.float(), rtol=2e-2, atol=1e-2 * scale)
