@@ -2,8 +2,8 @@
 // at most 64 rows in total (S = batch tokens of a generation step).  The job is pure weight streaming -- every weight
 // byte is used by at most a few dozen rows -- so the tiled kernel's LDS ring buys nothing and its coarse tiles leave
 // CUs idle (a CU draws only ~25 GB/s from HBM).  Here:
-//   * one block owns 16 output columns (16 W rows; the gated form also the 16 partner rows) of one group and splits K
-//     over its 1-8 waves, so a launch has G * N/16 blocks and ~16 wave-tasks per CU, all resident at once;
+//   * one block owns 16 output columns (gated: 32 columns = 32 + 32 weight rows, so that one X fragment load serves
+//     4 weight fragments) of one group and splits K over its 1-8 waves: ~8-16 wave-tasks per CU, all resident at once;
 //   * weights go global -> registers (16 B per lane, 8 loads in flight per lane), never through LDS; the few X rows
 //     are re-read from L1/L2;
 //   * v_mfma_f32_16x16x32_bf16 does the arithmetic (D = Wfrag x Xfrag, 16 columns x 16 rows per instruction, up to four
@@ -21,17 +21,35 @@ __device__ __forceinline__ bf16x8_t ld16(const bf16_t *p) {
     return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(p));
 }
 
+// NW = 16-column groups per block: one X fragment load serves NW (x2 when gated) weight fragments.
+// Measured (rocprofv3, S = 32, StableLM block, cold weights): the gated fc1 is fastest with 2 column groups per block
+// and K split in 2 (41 us; 47 us with 1 group), the plain fc2 (few columns, long K) with 1 group, 8 K steps in flight
+// and K split in 8 (31 us; 36-38 us with 4 groups).
+template <int EPI>
+struct SkinnyCfg {
+    static constexpr bool GATED = (EPI == EPI_SWIGLU);
+    static constexpr int NACC = GATED ? 2 : 1;
+    static constexpr int NW = GATED ? 2 : 1;        // 16-column groups per block
+    static constexpr int U = GATED ? 2 : 8;         // K steps in flight: 8 weight loads (8 KiB per wave) either way
+    static constexpr int COLS = 16 * NW;            // output columns per block
+};
+
 template <int EPI, int RT, int KSPLIT>
 __device__ __forceinline__ void skinny_body(const GemmParams &p, int grp, int row_begin, int n_rows, int ctile, float *red) {
-    constexpr bool GATED = (EPI == EPI_SWIGLU);
-    constexpr int NACC = GATED ? 2 : 1;
+    using C = SkinnyCfg<EPI>;
+    constexpr bool GATED = C::GATED;
+    constexpr int NACC = C::NACC, NW = C::NW, U = C::U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int expert = grp % p.n_experts;
     const bf16_t *wbase = p.w + (long long)expert * p.w_expert_stride;
-    const int c_ld = min(ctile * 16 + fr, p.N_out - 1);           // W row this lane loads (clamped, never stored)
-    const bf16_t *wa = wbase + (long long)c_ld * p.K + fq * 8;
-    const bf16_t *wb = GATED ? wa + (long long)p.b_row_offset * p.K : wa;
+    const bf16_t *wa[NW];
+#pragma unroll
+    for (int g = 0; g < NW; ++g) {
+        const int c_ld = min(ctile * C::COLS + g * 16 + fr, p.N_out - 1);  // W row this lane loads (clamped, never stored)
+        wa[g] = wbase + (long long)c_ld * p.K + fq * 8;
+    }
+    const long long b_off = GATED ? (long long)p.b_row_offset * p.K : 0;   // partner ('b') rows of the gated form
     const bf16_t *xr[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -40,106 +58,117 @@ __device__ __forceinline__ void skinny_body(const GemmParams &p, int grp, int ro
         const long long srow = p.gather ? (long long)(p.gather[prow] >> p.gather_shift) : (long long)prow;
         xr[t] = p.a + srow * p.lda + fq * 8;
     }
-    f32x4_t acc[NACC][RT];
+    f32x4_t acc[NACC][NW][RT];
 #pragma unroll
     for (int h = 0; h < NACC; ++h)
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[h][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < NW; ++g)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[h][g][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // this wave's share of K, in steps of 32
+    // this wave's share of K, in steps of 32 (every address below stays inside [0, K) of its row: s < K/32)
     const int nk = p.K / 32;
     const int k_lo = (wave * nk) / KSPLIT, k_hi = ((wave + 1) * nk) / KSPLIT;
-    constexpr int U = GATED ? 4 : 8;   // 8 weight loads (8 KiB per wave) in flight either way
     int s = k_lo;
     for (; s + U <= k_hi; s += U) {
-        bf16x8_t fa[U], fb[U], fx[U][RT];
+        bf16x8_t fw[U][NACC][NW], fx[U][RT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            fa[u] = ld16(wa + (s + u) * 32);
-            if (GATED) fb[u] = ld16(wb + (s + u) * 32);
+#pragma unroll
+            for (int g = 0; g < NW; ++g) {
+                fw[u][0][g] = ld16(wa[g] + (s + u) * 32);
+                if (GATED) fw[u][NACC - 1][g] = ld16(wa[g] + b_off + (s + u) * 32);
+            }
 #pragma unroll
             for (int t = 0; t < RT; ++t) fx[u][t] = ld16(xr[t] + (s + u) * 32);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[u], fx[u][t], acc[0][t], 0, 0, 0);
-                if (GATED) acc[NACC - 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fx[u][t], acc[NACC - 1][t], 0, 0, 0);
-            }
+            for (int h = 0; h < NACC; ++h)
+#pragma unroll
+                for (int g = 0; g < NW; ++g)
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+                        acc[h][g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[u][h][g], fx[u][t], acc[h][g][t], 0, 0, 0);
     }
     for (; s < k_hi; ++s) {
-        const bf16x8_t fa = ld16(wa + s * 32);
-        const bf16x8_t fb = GATED ? ld16(wb + s * 32) : fa;
+        bf16x8_t fx[RT];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const bf16x8_t fx = ld16(xr[t] + s * 32);
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fx, acc[0][t], 0, 0, 0);
-            if (GATED) acc[NACC - 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fx, acc[NACC - 1][t], 0, 0, 0);
+        for (int t = 0; t < RT; ++t) fx[t] = ld16(xr[t] + s * 32);
+#pragma unroll
+        for (int g = 0; g < NW; ++g) {
+            const bf16x8_t fa = ld16(wa[g] + s * 32);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[0][g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fx[t], acc[0][g][t], 0, 0, 0);
+            if (GATED) {
+                const bf16x8_t fb = ld16(wa[g] + b_off + s * 32);
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+                    acc[NACC - 1][g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fx[t], acc[NACC - 1][g][t], 0, 0, 0);
+            }
         }
     }
-    // ---- K partials -> LDS, wave 0 reduces in wave order (deterministic) ----
-    // red[wave][h][t][lane][4]
-#pragma unroll
-    for (int h = 0; h < NACC; ++h)
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-            *reinterpret_cast<float4 *>(red + (((wave * NACC + h) * RT + t) * 64 + lane) * 4) =
-                make_float4(acc[h][t][0], acc[h][t][1], acc[h][t][2], acc[h][t][3]);
-    __syncthreads();
-    if (wave != 0) return;
-    const int c0 = ctile * 16 + fq * 4;  // this lane's 4 consecutive output columns
-    if (c0 >= p.N_out) return;
+    // ---- K partials meet in LDS one 16-row tile at a time (red = KSPLIT x NACC x NW KiB); wave 0 sums them in
+    //      wave order (deterministic), applies bias / activation and stores ----
     const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
-    float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ba[j] = bf2f(bias[c0 + j]);
-            if (GATED) bb[j] = bf2f(bias[p.b_row_offset + c0 + j]);
-        }
-    }
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-        float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (t > 0) __syncthreads();  // wave 0 is done reading the previous tile's partials
 #pragma unroll
-        for (int w = 0; w < KSPLIT; ++w) {
-            const float4 va = *reinterpret_cast<const float4 *>(red + (((w * NACC + 0) * RT + t) * 64 + lane) * 4);
-            sa[0] += va.x; sa[1] += va.y; sa[2] += va.z; sa[3] += va.w;
-            if (GATED) {
-                const float4 vb = *reinterpret_cast<const float4 *>(red + (((w * NACC + 1) * RT + t) * 64 + lane) * 4);
-                sb[0] += vb.x; sb[1] += vb.y; sb[2] += vb.z; sb[3] += vb.w;
+        for (int h = 0; h < NACC; ++h)
+#pragma unroll
+            for (int g = 0; g < NW; ++g)
+                *reinterpret_cast<float4 *>(red + (((wave * NACC + h) * NW + g) * 64 + lane) * 4) =
+                    make_float4(acc[h][g][t][0], acc[h][g][t][1], acc[h][g][t][2], acc[h][g][t][3]);
+        __syncthreads();
+        if (wave == 0) {
+            const int r = t * 16 + fr;
+#pragma unroll
+            for (int g = 0; g < NW; ++g) {
+                const int c0 = ctile * C::COLS + g * 16 + fq * 4;  // this lane's 4 consecutive output columns
+                float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < KSPLIT; ++w) {
+                    const float4 va = *reinterpret_cast<const float4 *>(red + (((w * NACC + 0) * NW + g) * 64 + lane) * 4);
+                    sa[0] += va.x; sa[1] += va.y; sa[2] += va.z; sa[3] += va.w;
+                    if (GATED) {
+                        const float4 vb =
+                            *reinterpret_cast<const float4 *>(red + (((w * NACC + NACC - 1) * NW + g) * 64 + lane) * 4);
+                        sb[0] += vb.x; sb[1] += vb.y; sb[2] += vb.z; sb[3] += vb.w;
+                    }
+                }
+                if (r < n_rows && c0 < p.N_out) {  // N_out % 4 == 0: the 4 columns are valid together
+                    unsigned short hv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = rbf(sa[j] + (bias ? bf2f(bias[c0 + j]) : 0.f));  // bf16 output of the Linear
+                        if (GATED) {
+                            const float b = rbf(sb[j] + (bias ? bf2f(bias[p.b_row_offset + c0 + j]) : 0.f));
+                            hv[j] = swiglu_bf16(a, b, c0 + j < p.n_gated);
+                        } else {
+                            hv[j] = (EPI == EPI_GELU_NEW) ? f2bf(gelu_new_bf16(a)) : f2bf(a);
+                        }
+                    }
+                    uint2 o;
+                    o.x = (unsigned)hv[0] | ((unsigned)hv[1] << 16);
+                    o.y = (unsigned)hv[2] | ((unsigned)hv[3] << 16);
+                    *reinterpret_cast<uint2 *>(p.out + (long long)(row_begin + r) * p.ldo + c0) = o;
+                }
             }
         }
-        const int r = t * 16 + fr;
-        if (r >= n_rows) continue;
-        unsigned short hv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = rbf(sa[j] + ba[j]);  // bf16 output of the Linear
-            if (GATED) {
-                const float b = rbf(sb[j] + bb[j]);
-                hv[j] = swiglu_bf16(a, b, c0 + j < p.n_gated);
-            } else {
-                hv[j] = (EPI == EPI_GELU_NEW) ? f2bf(gelu_new_bf16(a)) : f2bf(a);
-            }
-        }
-        uint2 o;
-        o.x = (unsigned)hv[0] | ((unsigned)hv[1] << 16);
-        o.y = (unsigned)hv[2] | ((unsigned)hv[3] << 16);
-        *reinterpret_cast<uint2 *>(p.out + (long long)(row_begin + r) * p.ldo + c0) = o;  // N_out % 4 == 0
     }
 }
 
 template <int EPI, int KSPLIT>
 __global__ __launch_bounds__(64 * KSPLIT) void skinny_gemm_kernel(const GemmParams p) {
-    // K partials: waves x (1 or 2 halves) x 4 row tiles x 64 lanes x 4 floats
-    __shared__ __attribute__((aligned(16))) float red[KSPLIT * (EPI == EPI_SWIGLU ? 2 : 1) * 4 * 64 * 4];
+    using C = SkinnyCfg<EPI>;
+    __shared__ __attribute__((aligned(16))) float red[KSPLIT * C::NACC * C::NW * 64 * 4];  // KSPLIT x 4 KiB
     const int ctile = blockIdx.x % p.col_tiles;
     const int grp = blockIdx.x / p.col_tiles;
     const int b = p.group_offsets[grp], e = p.group_offsets[grp + 1];
     const int n = e - b;
-    if (n <= 0) return;                      // idle expert: its weights are not read
+    if (n <= 0) return;                      // idle expert: its weights are not read (uniform for the block)
     switch ((min(n, SKINNY_MAX_ROWS) + 15) >> 4) {
         case 1: skinny_body<EPI, 1, KSPLIT>(p, grp, b, min(n, 16), ctile, red); break;
         case 2: skinny_body<EPI, 2, KSPLIT>(p, grp, b, min(n, 32), ctile, red); break;
@@ -150,24 +179,24 @@ __global__ __launch_bounds__(64 * KSPLIT) void skinny_gemm_kernel(const GemmPara
 
 int launch_skinny_gemm(const GemmParams &p0, int epilogue, hipStream_t st) {
     GemmParams p = p0;
-    p.col_tiles = (p.N_out + 15) / 16;
+    const int cols = epilogue == MOE_EPI_SWIGLU ? SkinnyCfg<EPI_SWIGLU>::COLS : SkinnyCfg<EPI_PLAIN>::COLS;
+    p.col_tiles = (p.N_out + cols - 1) / cols;
     const long long grid = (long long)p.G * p.col_tiles;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffffLL) return fail(MOE_ERR_SHAPE, "skinny_gemm: grid too large");
     // K split over the waves of a block so that the launch has ~16 wave-tasks per CU (enough loads in flight to cover
     // the HBM latency) but not more than one round of resident waves (a second, partial round would double the time)
     int ks = 8;
-    while (ks > 1 && grid * ks > 4096) ks >>= 1;
+    while (ks > 1 && grid * ks > (epilogue == MOE_EPI_SWIGLU ? 2048 : 4096)) ks >>= 1;
     if (const char *env = getenv("MOE_SKINNY_KS")) {  // tuning knob: force the K split (1, 2, 4, 8)
         const int v = atoi(env);
         if (v == 1 || v == 2 || v == 4 || v == 8) ks = v;
     }
-    if (epilogue == MOE_EPI_SWIGLU && ks > 4) ks = 4;  // LDS for the gated partials
     const dim3 g((unsigned)grid), b(64 * ks);
 #define LAUNCH_SK(E_, K_) hipLaunchKernelGGL((skinny_gemm_kernel<E_, K_>), g, b, 0, st, p)
 #define LAUNCH_SK_ALL(E_)                                  \
     switch (ks) {                                          \
-        case 8: if (E_ != EPI_SWIGLU) { LAUNCH_SK(E_ == EPI_SWIGLU ? EPI_PLAIN : E_, 8); break; } \
+        case 8: LAUNCH_SK(E_, 8); break;                   \
         case 4: LAUNCH_SK(E_, 4); break;                   \
         case 2: LAUNCH_SK(E_, 2); break;                   \
         default: LAUNCH_SK(E_, 1); break;                  \
