@@ -112,7 +112,7 @@ class Experts(nn.Module):
         if cached is not None and len(cached) == len(self.deepspeed_experts):
             ng = _repa_gated(self.deepspeed_experts[0]) if cached[0].act == ops.ACT_SWIGLU else -1
             if ng == cached[0].n_gated:
-                self.n_gated = ng
+                self.__dict__["n_gated"] = ng   # plain attribute: skip nn.Module.__setattr__ on the hot path
                 return cached
         specs = [describe_expert(e) for e in self.deepspeed_experts]
         a0, n0 = specs[0].act, len(specs[0].fc1)
@@ -127,9 +127,11 @@ class Experts(nn.Module):
         ps = []
         for s in specs:
             for lin in s.fc1 + [s.fc2]:
-                ps.append(lin.weight)
-                if lin.bias is not None:
-                    ps.append(lin.bias)
+                pd = lin._parameters                  # direct dict access: nn.Module.__getattr__ is slow on this path
+                ps.append(pd["weight"])
+                b = pd.get("bias")
+                if b is not None:
+                    ps.append(b)
         return ps
 
     def packed(self, device: torch.device):

@@ -5,7 +5,6 @@ Nothing here computes on the CPU or in eager torch; a missing library raises (``
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
 from typing import Optional
 
 import torch
@@ -49,8 +48,34 @@ class PhaseTimer:
         return out
 
 
+_STREAM_SCOPE = None   # (device index, stream pointer) while MOELayer runs one forward; saves repeated lookups
+
+
 def _stream_ptr(t: Tensor) -> int:
+    sc = _STREAM_SCOPE
+    if sc is not None and sc[0] == t.device.index:
+        return sc[1]
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class stream_scope:
+    """``with stream_scope(x):`` -- look the current stream of x's device up once for all ops inside (the stream must
+    not be switched inside the block).  At decode sizes the host side of a call costs as much as its GPU side."""
+
+    def __init__(self, t: Tensor):
+        self.t = t
+
+    def __enter__(self):
+        global _STREAM_SCOPE
+        self.prev = _STREAM_SCOPE
+        if self.t.is_cuda:
+            _STREAM_SCOPE = (self.t.device.index, torch.cuda.current_stream(self.t.device).cuda_stream)
+        return self
+
+    def __exit__(self, *a):
+        global _STREAM_SCOPE
+        _STREAM_SCOPE = self.prev
+        return False
 
 
 class _NullCtx:
@@ -85,24 +110,81 @@ def _need(t: Tensor, name: str, dtype, ndim: Optional[int] = None) -> None:
         raise ValueError(f"{name}: must be contiguous")
 
 
-@dataclass
-class Routing:
-    """Index-form routing result (SURVEY 8a').  All tensors live on the device."""
-    expert_idx: Tensor      # [S,2] int32
-    slot: Tensor            # [S,2] int32, -1 = dropped
-    weight: Tensor          # [S,2] fp32
-    exp_counts: Tensor      # [E] int64 (pre-drop)
-    kept_counts: Tensor     # [E] int32
-    expert_offsets: Tensor  # [E+1] int32
-    perm: Tensor            # [max_rows] int32, token*2+choice
-    l_aux: Tensor           # 0-dim fp32
-    max_rows: int           # host bound on expert_offsets[E]
-    capacity: int
-    used_token: Optional[Tensor] = None   # [S] int32 mask given to top-1 routing (kept for the backward pass)
+_ROUTING_FIELDS = ("expert_idx", "slot", "weight", "exp_counts", "kept_counts", "expert_offsets", "perm", "l_aux")
 
-    @property
-    def top_k(self) -> int:
-        return self.expert_idx.shape[1]
+
+def _pad16(n: int) -> int:
+    return (n + 15) & ~15
+
+
+class Routing:
+    """Index-form routing result (SURVEY 8a').  All arrays live on the device:
+
+        expert_idx [S,k] int32 · slot [S,k] int32 (-1 = dropped) · weight [S,k] fp32 · exp_counts [E] int64 (pre-drop)
+        kept_counts [E] int32 · expert_offsets [E+1] int32 · perm [max_rows] int32 (token*k + choice) · l_aux 0-dim fp32
+
+    The kernels' outputs sit in ONE allocation; the tensor attributes above are views created on first access (the
+    launches only need the addresses, ``ptr(name)``), which keeps the per-call host cost low.  A Routing can also be
+    built from ready-made tensors (tests, CPU rehearsals): ``Routing(expert_idx, slot, weight, exp_counts, kept_counts,
+    expert_offsets, perm, l_aux, max_rows, capacity)``."""
+
+    def __init__(self, expert_idx=None, slot=None, weight=None, exp_counts=None, kept_counts=None, expert_offsets=None,
+                 perm=None, l_aux=None, max_rows: int = 0, capacity: int = 0, used_token: Optional[Tensor] = None):
+        self._views = {}
+        for name, t in zip(_ROUTING_FIELDS, (expert_idx, slot, weight, exp_counts, kept_counts, expert_offsets, perm, l_aux)):
+            if t is not None:
+                self._views[name] = t
+        self._arena = None
+        self._layout = None
+        self.max_rows = int(max_rows)      # host bound on expert_offsets[E]
+        self.capacity = int(capacity)
+        self.used_token = used_token       # [S] int32 mask given to top-1 routing (kept for the backward pass)
+        self.S = expert_idx.shape[0] if expert_idx is not None else 0
+        self.E = exp_counts.numel() if exp_counts is not None else 0
+        self.top_k = expert_idx.shape[1] if expert_idx is not None else 0
+
+    @classmethod
+    def allocate(cls, S: int, E: int, k: int, max_rows: int, capacity: int, ws_bytes: int, dev, used_token=None):
+        """One device allocation for every routing output + the kernel's workspace."""
+        r = cls.__new__(cls)
+        lay, off = {}, 0
+        for name, nbytes, dtype, shape in (
+                ("expert_idx", S * k * 4, torch.int32, (S, k)), ("slot", S * k * 4, torch.int32, (S, k)),
+                ("weight", S * k * 4, torch.float32, (S, k)), ("exp_counts", E * 8, torch.int64, (E,)),
+                ("kept_counts", E * 4, torch.int32, (E,)), ("expert_offsets", (E + 1) * 4, torch.int32, (E + 1,)),
+                ("perm", max(max_rows, 1) * 4, torch.int32, (max(max_rows, 1),)), ("l_aux", 4, torch.float32, ()),
+                ("workspace", ws_bytes, torch.uint8, (ws_bytes,))):
+            lay[name] = (off, nbytes, dtype, shape)
+            off = _pad16(off + nbytes)
+        r._arena = torch.empty((max(off, 16),), dtype=torch.uint8, device=dev)
+        r._base = r._arena.data_ptr()
+        r._layout = lay
+        r._views = {}
+        r.max_rows, r.capacity, r.used_token = int(max_rows), int(capacity), used_token
+        r.S, r.E, r.top_k = S, E, k
+        return r
+
+    def ptr(self, name: str) -> int:
+        if self._layout is not None:
+            return self._base + self._layout[name][0]
+        return self._views[name].data_ptr()
+
+    def _view(self, name: str) -> Tensor:
+        v = self._views.get(name)
+        if v is None:
+            off, nbytes, dtype, shape = self._layout[name]
+            v = self._arena[off:off + nbytes].view(dtype).view(shape)
+            self._views[name] = v
+        return v
+
+    expert_idx = property(lambda self: self._view("expert_idx"))
+    slot = property(lambda self: self._view("slot"))
+    weight = property(lambda self: self._view("weight"))
+    exp_counts = property(lambda self: self._view("exp_counts"))
+    kept_counts = property(lambda self: self._view("kept_counts"))
+    expert_offsets = property(lambda self: self._view("expert_offsets"))
+    perm = property(lambda self: self._view("perm"))
+    l_aux = property(lambda self: self._view("l_aux"))
 
 
 def gate_logits(x: Tensor, wg_weight: Tensor) -> Tensor:
@@ -138,26 +220,17 @@ def routing_top2(logits: Tensor, capacity: int, noise: Optional[Tensor] = None,
             raise ValueError("noise must match logits in shape and device")
     dev = logits.device
     max_rows = min(2 * S, E * int(capacity)) if drop_tokens else 2 * S
-    i32 = dict(dtype=torch.int32, device=dev)
-    expert_idx = torch.empty((S, 2), **i32)
-    slot = torch.empty((S, 2), **i32)
-    weight = torch.empty((S, 2), dtype=torch.float32, device=dev)
-    exp_counts = torch.empty((E,), dtype=torch.int64, device=dev)
-    kept = torch.empty((E,), **i32)
-    offs = torch.empty((E + 1,), **i32)
-    perm = torch.empty((max(max_rows, 1),), **i32)
-    l_aux = torch.empty((), dtype=torch.float32, device=dev)
     lib = _lib.load()
     ws_bytes = lib.moe_routing_workspace_bytes(S, E)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    r = Routing.allocate(S, E, 2, max_rows, int(capacity), ws_bytes, dev)
     with _on(dev):
         rc = lib.moe_routing_top2_fwd(logits.data_ptr(), noise.data_ptr() if noise is not None else None,
                                       int(noise_seed) & 0xFFFFFFFFFFFFFFFF, S, E, int(capacity), int(bool(drop_tokens)),
-                                      expert_idx.data_ptr(), slot.data_ptr(), weight.data_ptr(),
-                                      exp_counts.data_ptr(), kept.data_ptr(), offs.data_ptr(), perm.data_ptr(),
-                                      l_aux.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(logits))
+                                      r.ptr("expert_idx"), r.ptr("slot"), r.ptr("weight"), r.ptr("exp_counts"),
+                                      r.ptr("kept_counts"), r.ptr("expert_offsets"), r.ptr("perm"), r.ptr("l_aux"),
+                                      r.ptr("workspace"), ws_bytes, _stream_ptr(logits))
     _lib.check(rc, "moe_routing_top2_fwd")
-    return Routing(expert_idx, slot, weight, exp_counts, kept, offs, perm, l_aux, max_rows, int(capacity))
+    return r
 
 
 def routing_top1(logits: Tensor, capacity: int, used_token: Optional[Tensor] = None, use_rts: bool = True,
@@ -181,39 +254,24 @@ def routing_top1(logits: Tensor, capacity: int, used_token: Optional[Tensor] = N
             raise ValueError("used_token must have one entry per token, on the logits' device")
         ut = (used_token.reshape(-1) != 0).to(torch.int32).contiguous()
     max_rows = min(S, E * int(capacity)) if drop_tokens else S
-    i32 = dict(dtype=torch.int32, device=dev)
-    expert_idx = torch.empty((S, 1), **i32)
-    slot = torch.empty((S, 1), **i32)
-    weight = torch.empty((S, 1), dtype=torch.float32, device=dev)
-    exp_counts = torch.empty((E,), dtype=torch.int64, device=dev)
-    kept = torch.empty((E,), **i32)
-    offs = torch.empty((E + 1,), **i32)
-    perm = torch.empty((max(max_rows, 1),), **i32)
-    l_aux = torch.empty((), dtype=torch.float32, device=dev)
     lib = _lib.load()
     ws_bytes = lib.moe_routing_top1_workspace_bytes(S, E)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    r = Routing.allocate(S, E, 1, max_rows, int(capacity), ws_bytes, dev, used_token=ut)
     with _on(dev):
         rc = lib.moe_routing_top1_fwd(
             logits.data_ptr(), noise.data_ptr() if noise is not None else None, int(noise_seed) & 0xFFFFFFFFFFFFFFFF,
             ut.data_ptr() if ut is not None else None, rts_uniform.data_ptr() if rts_uniform is not None else None,
             int(rts_seed) & 0xFFFFFFFFFFFFFFFF, int(bool(use_rts)), S, E, int(capacity), int(bool(drop_tokens)),
-            expert_idx.data_ptr(), slot.data_ptr(), weight.data_ptr(), exp_counts.data_ptr(), kept.data_ptr(),
-            offs.data_ptr(), perm.data_ptr(), l_aux.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(logits))
+            r.ptr("expert_idx"), r.ptr("slot"), r.ptr("weight"), r.ptr("exp_counts"), r.ptr("kept_counts"),
+            r.ptr("expert_offsets"), r.ptr("perm"), r.ptr("l_aux"), r.ptr("workspace"), ws_bytes, _stream_ptr(logits))
     _lib.check(rc, "moe_routing_top1_fwd")
-    return Routing(expert_idx, slot, weight, exp_counts, kept, offs, perm, l_aux, max_rows, int(capacity), ut)
+    return r
 
 
-def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
-               w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
-               group_offsets: Tensor, max_rows: int, timer: Optional["PhaseTimer"] = None,
-               n_gated: int = -1) -> Tensor:
-    """Grouped expert MLP over compact rows; returns y [max_rows, M] bf16 (rows past the device-side
-    group_offsets[G] are left unwritten)."""
+def _check_ffn_weights(act, a, w1, b1, w2, b2):
     _need(a, "a", torch.bfloat16, 2)
     _need(w1, "w1", torch.bfloat16, 3)
     _need(w2, "w2", torch.bfloat16, 3)
-    _need(group_offsets, "group_offsets", torch.int32, 1)
     M = a.shape[1]
     n_local, M2, I = w2.shape
     n1 = 2 * I if act == ACT_SWIGLU else I
@@ -224,6 +282,53 @@ def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
             _need(b, name, torch.bfloat16, 2)
             if tuple(b.shape) != (n_local, n):
                 raise ValueError(f"{name}: expected {(n_local, n)}, got {tuple(b.shape)}")
+            if b.device != a.device:
+                raise ValueError("all operands must be on the same device")
+    if w1.device != a.device or w2.device != a.device:
+        raise ValueError("all operands must be on the same device")
+    return M, I, n_local
+
+
+def _expert_ffn_launch(act, a, gather_ptr, gather_shift, w1, b1, w2, b2, offs_ptr, G, max_rows, M, I, n_local, timer,
+                       n_gated):
+    dev = a.device
+    y = torch.empty((max(max_rows, 1), M), dtype=torch.bfloat16, device=dev)
+    if max_rows == 0:
+        return y
+    h = torch.empty((max_rows, I), dtype=torch.bfloat16, device=dev)
+    lib = _lib.load()
+    b1p = b1.data_ptr() if b1 is not None else None
+    b2p = b2.data_ptr() if b2 is not None else None
+    st = _stream_ptr(a)
+    with _on(dev):
+        if timer is None:
+            rc = lib.moe_expert_ffn_fwd(act, a.data_ptr(), a.stride(0), gather_ptr, gather_shift, w1.data_ptr(), b1p,
+                                        w2.data_ptr(), b2p, offs_ptr, G, n_local, max_rows, M, I, n_gated, h.data_ptr(),
+                                        y.data_ptr(), st)
+            _lib.check(rc, "moe_expert_ffn_fwd")
+        else:
+            # same two launches through the single-GEMM primitive, with events between them
+            epi = EPI_SWIGLU if act == ACT_SWIGLU else EPI_GELU_NEW
+            timer.mark("fc1_begin")
+            rc = lib.moe_grouped_gemm_fwd(epi, a.data_ptr(), a.stride(0), gather_ptr, gather_shift, w1.data_ptr(), b1p,
+                                          offs_ptr, G, n_local, max_rows, M, I, n_gated, h.data_ptr(), I, st)
+            _lib.check(rc, "moe_grouped_gemm_fwd(fc1)")
+            timer.mark("fc1_end")
+            rc = lib.moe_grouped_gemm_fwd(EPI_PLAIN, h.data_ptr(), I, None, 0, w2.data_ptr(), b2p, offs_ptr, G, n_local,
+                                          max_rows, I, M, -1, y.data_ptr(), M, st)
+            _lib.check(rc, "moe_grouped_gemm_fwd(fc2)")
+            timer.mark("fc2_end")
+    return y
+
+
+def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
+               w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
+               group_offsets: Tensor, max_rows: int, timer: Optional["PhaseTimer"] = None,
+               n_gated: int = -1) -> Tensor:
+    """Grouped expert MLP over compact rows; returns y [max_rows, M] bf16 (rows past the device-side
+    group_offsets[G] are left unwritten)."""
+    M, I, n_local = _check_ffn_weights(act, a, w1, b1, w2, b2)
+    _need(group_offsets, "group_offsets", torch.int32, 1)
     G = group_offsets.numel() - 1
     if G < 1:
         raise ValueError("group_offsets needs at least 2 entries")
@@ -233,39 +338,22 @@ def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
             raise ValueError("gather shorter than max_rows")
     elif a.shape[0] < max_rows:
         raise ValueError("a has fewer rows than max_rows")
-    for t in (w1, w2, group_offsets, gather, b1, b2):
+    for t in (group_offsets, gather):
         if t is not None and t.device != a.device:
             raise ValueError("all operands must be on the same device")
-    dev = a.device
-    y = torch.empty((max(max_rows, 1), M), dtype=torch.bfloat16, device=dev)
-    if max_rows == 0:
-        return y
-    h = torch.empty((max_rows, I), dtype=torch.bfloat16, device=dev)
-    lib = _lib.load()
-    gp = gather.data_ptr() if gather is not None else None
-    b1p = b1.data_ptr() if b1 is not None else None
-    b2p = b2.data_ptr() if b2 is not None else None
-    with _on(dev):
-        if timer is None:
-            rc = lib.moe_expert_ffn_fwd(act, a.data_ptr(), a.stride(0), gp, gather_shift, w1.data_ptr(), b1p,
-                                        w2.data_ptr(), b2p, group_offsets.data_ptr(), G, n_local, max_rows, M, I,
-                                        n_gated, h.data_ptr(), y.data_ptr(), _stream_ptr(a))
-            _lib.check(rc, "moe_expert_ffn_fwd")
-        else:
-            # same two launches through the single-GEMM primitive, with events between them
-            epi = EPI_SWIGLU if act == ACT_SWIGLU else EPI_GELU_NEW
-            timer.mark("fc1_begin")
-            rc = lib.moe_grouped_gemm_fwd(epi, a.data_ptr(), a.stride(0), gp, gather_shift, w1.data_ptr(), b1p,
-                                          group_offsets.data_ptr(), G, n_local, max_rows, M, I, n_gated, h.data_ptr(), I,
-                                          _stream_ptr(a))
-            _lib.check(rc, "moe_grouped_gemm_fwd(fc1)")
-            timer.mark("fc1_end")
-            rc = lib.moe_grouped_gemm_fwd(EPI_PLAIN, h.data_ptr(), I, None, 0, w2.data_ptr(), b2p,
-                                          group_offsets.data_ptr(), G, n_local, max_rows, I, M, -1, y.data_ptr(), M,
-                                          _stream_ptr(a))
-            _lib.check(rc, "moe_grouped_gemm_fwd(fc2)")
-            timer.mark("fc2_end")
-    return y
+    return _expert_ffn_launch(act, a, gather.data_ptr() if gather is not None else None, gather_shift, w1, b1, w2, b2,
+                              group_offsets.data_ptr(), G, max_rows, M, I, n_local, timer, n_gated)
+
+
+def expert_ffn_routed(act: int, x: Tensor, r: Routing, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
+                      timer: Optional["PhaseTimer"] = None, n_gated: int = -1) -> Tensor:
+    """``expert_ffn`` over the rows a Routing dispatched (gather through its perm, one group per expert), taking the
+    addresses straight from the routing arena."""
+    M, I, n_local = _check_ffn_weights(act, x, w1, b1, w2, b2)
+    if n_local != r.E:
+        raise ValueError(f"{n_local} local experts but the routing has {r.E}")
+    return _expert_ffn_launch(act, x, r.ptr("perm"), r.top_k - 1, w1, b1, w2, b2, r.ptr("expert_offsets"), r.E, r.max_rows,
+                              M, I, n_local, timer, n_gated)
 
 
 def gather_rows(src: Tensor, gather: Tensor, gather_shift: int, n_rows_dev: Tensor, max_rows: int) -> Tensor:
@@ -289,14 +377,13 @@ def combine(y: Tensor, r: Routing, S: int, M: int) -> Tensor:
     _need(y, "y", torch.bfloat16, 2)
     if y.shape[1] != M or y.shape[0] < r.max_rows:
         raise ValueError(f"y {tuple(y.shape)} too small for max_rows={r.max_rows}, M={M}")
-    if r.expert_idx.shape[0] != S:
+    if r.S != S:
         raise ValueError("routing does not match S")
     out = torch.empty((S, M), dtype=torch.bfloat16, device=y.device)
     lib = _lib.load()
     with _on(y.device):
-        rc = lib.moe_combine_fwd(y.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(), r.weight.data_ptr(),
-                                 r.expert_offsets.data_ptr(), S, M, r.expert_idx.shape[1], out.data_ptr(),
-                                 _stream_ptr(y))
+        rc = lib.moe_combine_fwd(y.data_ptr(), r.ptr("expert_idx"), r.ptr("slot"), r.ptr("weight"),
+                                 r.ptr("expert_offsets"), S, M, r.top_k, out.data_ptr(), _stream_ptr(y))
     _lib.check(rc, "moe_combine_fwd")
     return out
 
@@ -390,12 +477,12 @@ def combine_bwd(dout: Tensor, y: Tensor, r: Routing, S: int, M: int):
     if tuple(dout.shape) != (S, M) or y.shape[1] != M:
         raise ValueError("dout / y shapes do not match")
     dy = torch.empty_like(y)
-    k = r.expert_idx.shape[1]
+    k = r.top_k
     dweight = torch.empty((S, k), dtype=torch.float32, device=y.device)
     lib = _lib.load()
     with _on(y.device):
-        rc = lib.moe_combine_bwd(dout.data_ptr(), y.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(),
-                                 r.weight.data_ptr(), r.expert_offsets.data_ptr(), S, M, k, dy.data_ptr(),
+        rc = lib.moe_combine_bwd(dout.data_ptr(), y.data_ptr(), r.ptr("expert_idx"), r.ptr("slot"),
+                                 r.ptr("weight"), r.ptr("expert_offsets"), S, M, k, dy.data_ptr(),
                                  dweight.data_ptr(), _stream_ptr(y))
     _lib.check(rc, "moe_combine_bwd")
     return dy, dweight
@@ -416,7 +503,7 @@ def gate_bwd(x: Tensor, logits: Tensor, r: Routing, dweight: Tensor, dl_aux: Opt
     nws = lib.moe_gate_bwd_workspace_bytes(S, M, E)
     ws = torch.empty((nws,), dtype=torch.uint8, device=x.device)
     with _on(x.device):
-        rc = lib.moe_gate_bwd(x.data_ptr(), logits.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(),
+        rc = lib.moe_gate_bwd(x.data_ptr(), logits.data_ptr(), r.ptr("expert_idx"), r.ptr("slot"),
                               dweight.data_ptr(), dl_aux.data_ptr() if dl_aux is not None else None,
                               r.used_token.data_ptr() if r.used_token is not None else None, S, M, E, r.top_k,
                               dlogits.data_ptr(), dwg.data_ptr(), ws.data_ptr(), nws, _stream_ptr(x))
@@ -428,15 +515,15 @@ def dispatch_bwd(da_rows: Tensor, r: Routing, dlogits: Optional[Tensor], wg_weig
                  S: int, M: int) -> Tensor:
     """dx [S,M] bf16: sum of the token's compact-row gradients + the gate term dlogits @ wg."""
     _need(da_rows, "da_rows", torch.bfloat16, 2)
-    E = r.exp_counts.numel()
+    E = r.E
     dx = torch.empty((S, M), dtype=torch.bfloat16, device=da_rows.device)
     lib = _lib.load()
     with _on(da_rows.device):
-        rc = lib.moe_dispatch_bwd(da_rows.data_ptr(), r.expert_idx.data_ptr(), r.slot.data_ptr(),
-                                  r.expert_offsets.data_ptr(),
+        rc = lib.moe_dispatch_bwd(da_rows.data_ptr(), r.ptr("expert_idx"), r.ptr("slot"),
+                                  r.ptr("expert_offsets"),
                                   dlogits.data_ptr() if dlogits is not None else None,
                                   wg_weight.data_ptr() if wg_weight is not None else None,
                                   int(wg_weight is not None and wg_weight.dtype == torch.bfloat16), S, M, E,
-                                  r.expert_idx.shape[1], dx.data_ptr(), _stream_ptr(da_rows))
+                                  r.top_k, dx.data_ptr(), _stream_ptr(da_rows))
     _lib.check(rc, "moe_dispatch_bwd")
     return dx

@@ -82,7 +82,7 @@ class TopKGate(nn.Module):
         if self.k == 2 and used_token is not None:
             raise NotImplementedError("used_token is ignored by upstream top2gating; pass it only with k=1")
         lg = self.logits(x)
-        self.last_logits = lg            # kept for the backward pass (and for inspection)
+        self.__dict__["last_logits"] = lg   # kept for the backward pass (plain attribute, fast path)
         S, E = lg.shape
         cf = self.capacity_factor if self.training else self.eval_capacity_factor
         if self.k == 1:
@@ -209,7 +209,9 @@ class MOELayer(nn.Module):
                 # because the reference adds it to the loss (llava_stablelm_moe.py:461-472)
                 out, self.l_aux = _MoEBlockFn.apply(self, used_token, x_in, wg, *params)
                 return out
-        out, self.l_aux, _ = self._run(x_in, used_token, save=False)
+        with ops.stream_scope(x_in):
+            out, l_aux, _ = self._run(x_in, used_token, save=False)
+        self.__dict__["l_aux"] = l_aux
         return out
 
     def _run(self, x_in: Tensor, used_token, save: bool):
@@ -226,7 +228,8 @@ class MOELayer(nn.Module):
         r = self.gate(x, used_token)
         if t is not None:
             t.mark("gate_end")
-        self.exp_counts, self.last_routing = r.exp_counts, r
+        d = self.__dict__                  # plain attributes: nn.Module.__setattr__ is slow on this path
+        d["exp_counts"], d["last_routing"] = r.exp_counts, r
         act, w1, b1, w2, b2 = self.experts.packed(x.device)
         ng = self.experts.n_gated
         shift = r.top_k - 1                      # perm holds token * top_k + choice
@@ -236,8 +239,7 @@ class MOELayer(nn.Module):
                 y, ab, h = ops.expert_ffn_train(act, x, r.perm, shift, w1, b1, w2, b2, r.expert_offsets, r.max_rows, ng)
                 saved = dict(a=x, gather=r.perm, shift=shift, ab=ab, h=h, offs=r.expert_offsets, rows=r.max_rows)
             else:
-                y = ops.expert_ffn(act, x, r.perm, shift, w1, b1, w2, b2, r.expert_offsets, r.max_rows, timer=t,
-                                   n_gated=ng)
+                y = ops.expert_ffn_routed(act, x, r, w1, b1, w2, b2, timer=t, n_gated=ng)
         else:
             y, saved = self._expert_parallel(x, r, act, w1, b1, w2, b2, save)
         out = ops.combine(y, r, S, M)

@@ -176,6 +176,8 @@ def _install_cpu_stand_ins():
 
     ops.gate_logits, ops.routing_top2, ops.gather_rows = gate_logits, routing_top2, gather_rows
     ops.expert_ffn, ops.combine = expert_ffn, combine
+    ops.expert_ffn_routed = (lambda act, x, r, w1, b1, w2, b2, timer=None, n_gated=-1:
+                             expert_ffn(act, x, r.perm, r.top_k - 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows))
     ops.expert_ffn_train, ops.expert_ffn_bwd, ops.combine_bwd = expert_ffn_train, expert_ffn_bwd, combine_bwd
     ops.gate_bwd, ops.dispatch_bwd = gate_bwd, dispatch_bwd
 
