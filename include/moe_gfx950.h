@@ -164,6 +164,18 @@ int moe_gather_rows_fwd(const void *src, const int32_t *gather, int gather_shift
 int moe_combine_fwd(const void *y, const int32_t *expert_idx, const int32_t *slot, const float *weight,
                     const int32_t *expert_offsets, int S, int M, int top_k, void *out, void *stream);
 
+/* moe_block_top2_fwd: the whole block on one GPU in one call -- moe_gate_logits_fwd, moe_routing_top2_fwd,
+ * moe_expert_ffn_fwd (rows gathered through perm, one group per expert, max_rows = min(2S, E*capacity) or 2S without
+ * the drop) and moe_combine_fwd, in this order on `stream`, with exactly their argument meanings and buffers
+ * (h_ws [max_rows, I], y [max_rows, M], out [S, M]).  Replaces MOELayer.forward for ep_size == 1;
+ * a decode step's host cost is dominated by the number of calls, hence this one. */
+int moe_block_top2_fwd(const void *x_bf16, const void *wg, int wg_is_bf16, float *logits, const float *noise,
+                       uint64_t noise_seed, int S, int M, int E, int I, int act, int capacity, int drop_tokens,
+                       int n_gated, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
+                       int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
+                       void *routing_ws, size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2,
+                       const void *b2, void *h_ws, void *y, void *out, void *stream);
+
 /* ---- backward ---------------------------------------------------------------
  * Upstream has no hand-written backward: torch autograd differentiates top2gating, the two einsums, _AllToAll
  * (whose backward is the same all-to-all on the gradients) and the expert nn.Linear modules.  The reference trains

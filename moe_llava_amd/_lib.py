@@ -38,6 +38,10 @@ _SIGNATURES = [
     ("moe_gather_rows_fwd", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("moe_combine_fwd", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    ("moe_block_top2_fwd", c_int,
+     [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     # ---- backward ----
     ("moe_expert_ffn_fwd_train", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -11,7 +11,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmoe_gfx950.so")
-SOURCES = ["moe_routing.hip", "moe_routing_top1.hip", "moe_gemm.hip", "moe_gemv.hip", "moe_wgrad.hip", "moe_backward.hip"]
+SOURCES = ["moe_routing.hip", "moe_routing_top1.hip", "moe_gemm.hip", "moe_gemv.hip", "moe_wgrad.hip", "moe_backward.hip", "moe_block.hip"]
 
 
 def hipcc_path() -> str:

@@ -356,6 +356,45 @@ def expert_ffn_routed(act: int, x: Tensor, r: Routing, w1: Tensor, b1: Optional[
                               M, I, n_local, timer, n_gated)
 
 
+def block_top2(x: Tensor, wg_weight: Tensor, capacity: int, noise: Optional[Tensor], noise_seed: int, drop_tokens: bool,
+               act: int, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], n_gated: int = -1):
+    """Whole block on one GPU in one library call (gate -> top-2 routing -> expert FFN -> combine).
+    Returns (out [S,M] bf16, logits [S,E] fp32, Routing)."""
+    M, I, n_local = _check_ffn_weights(act, x, w1, b1, w2, b2)
+    if wg_weight.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"wg.weight: expected fp32 or bf16, got {wg_weight.dtype}")
+    _need(wg_weight, "wg.weight", wg_weight.dtype, 2)
+    S = x.shape[0]
+    E = wg_weight.shape[0]
+    if wg_weight.shape[1] != M or wg_weight.device != x.device or n_local != E:
+        raise ValueError("wg.weight / expert weights do not match x")
+    if noise is not None:
+        _need(noise, "noise", torch.float32, 2)
+        if tuple(noise.shape) != (S, E) or noise.device != x.device:
+            raise ValueError("noise must be [S, E] on x's device")
+    dev = x.device
+    max_rows = min(2 * S, E * int(capacity)) if drop_tokens else 2 * S
+    lib = _lib.load()
+    ws_bytes = lib.moe_routing_workspace_bytes(S, E)
+    r = Routing.allocate(S, E, 2, max_rows, int(capacity), ws_bytes, dev)
+    logits = torch.empty((S, E), dtype=torch.float32, device=dev)
+    rows = max(max_rows, 1)
+    hy = torch.empty((rows * (I + M),), dtype=torch.bfloat16, device=dev)   # h workspace, then y
+    out = torch.empty((S, M), dtype=torch.bfloat16, device=dev)
+    hp = hy.data_ptr()
+    with _on(dev):
+        rc = lib.moe_block_top2_fwd(
+            x.data_ptr(), wg_weight.data_ptr(), int(wg_weight.dtype == torch.bfloat16), logits.data_ptr(),
+            noise.data_ptr() if noise is not None else None, int(noise_seed) & 0xFFFFFFFFFFFFFFFF, S, M, E, I, act,
+            int(capacity), int(bool(drop_tokens)), n_gated, r.ptr("expert_idx"), r.ptr("slot"), r.ptr("weight"),
+            r.ptr("exp_counts"), r.ptr("kept_counts"), r.ptr("expert_offsets"), r.ptr("perm"), r.ptr("l_aux"),
+            r.ptr("workspace"), ws_bytes, w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
+            b2.data_ptr() if b2 is not None else None, hp, hp + rows * I * 2, out.data_ptr(), _stream_ptr(x))
+    _lib.check(rc, "moe_block_top2_fwd")
+    r._keep = hy                                   # y lives in hy; keep it alive with the routing (inspection only)
+    return out, logits, r
+
+
 def gather_rows(src: Tensor, gather: Tensor, gather_shift: int, n_rows_dev: Tensor, max_rows: int) -> Tensor:
     """dst[p] = src[gather[p] >> shift] for p < n_rows_dev[0] (expert-sorted send buffer of the EP all-to-all)."""
     _need(src, "src", torch.bfloat16, 2)

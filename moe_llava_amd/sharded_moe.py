@@ -84,9 +84,15 @@ class TopKGate(nn.Module):
         lg = self.logits(x)
         self.__dict__["last_logits"] = lg   # kept for the backward pass (plain attribute, fast path)
         S, E = lg.shape
-        cf = self.capacity_factor if self.training else self.eval_capacity_factor
         if self.k == 1:
+            cf = self.capacity_factor if self.training else self.eval_capacity_factor
             return self._top1(lg, cf, used_token)
+        cap, noise, seed = self._top2_args(S, E)
+        return ops.routing_top2(lg, cap, noise, self.drop_tokens, noise_seed=seed)
+
+    def _top2_args(self, S: int, E: int):
+        """(capacity, noise tensor or None, noise seed) of one top-2 routing call."""
+        cf = self.capacity_factor if self.training else self.eval_capacity_factor
         cap = capacity_of(S, E, cf * 2, self.min_capacity)
         noise, seed = None, 0
         if self.top2_2nd_expert_sampling:
@@ -95,8 +101,8 @@ class TopKGate(nn.Module):
             else:
                 # Gumbel noise is generated inside the routing kernel (Philox keyed by this seed); the seed comes
                 # from torch's CPU generator, so torch.manual_seed() makes runs reproducible and no launch is spent
-                seed = int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())
-        return ops.routing_top2(lg, cap, noise, self.drop_tokens, noise_seed=seed)
+                seed = _fresh_seed()
+        return cap, noise, seed
 
     def _top1(self, lg: Tensor, cf: float, used_token: Optional[Tensor]) -> ops.Routing:
         """Upstream top1gating: capacity from cf (not doubled), RSample noise on the choice, random
@@ -223,9 +229,23 @@ class MOELayer(nn.Module):
             x = x.contiguous()
         S = x.shape[0]
         t = self.timer
+        gate = self.gate
+        local = self.ep_size == 1 and not (self.force_exchange and self.ep_group is not None)
+        if (local and not save and t is None and used_token is None and gate.k == 2 and not gate.wg._forward_hooks
+                and gate.noisy_gate_policy is None):
+            # inference on one GPU: the whole block in ONE library call (a decode step is host-bound otherwise)
+            experts = self.experts
+            act, w1, b1, w2, b2 = experts.packed(x.device)
+            wgw = gate.wg.weight
+            cap, noise, seed = gate._top2_args(S, wgw.shape[0])
+            out, lg, r = ops.block_top2(x, wgw, cap, noise, seed, gate.drop_tokens, act, w1, b1, w2, b2, experts.n_gated)
+            gate.__dict__["last_logits"] = lg
+            d = self.__dict__
+            d["exp_counts"], d["last_routing"] = r.exp_counts, r
+            return out.reshape(x_in.shape), r.l_aux, None
         if t is not None:
             t.mark("gate_begin")
-        r = self.gate(x, used_token)
+        r = gate(x, used_token)
         if t is not None:
             t.mark("gate_end")
         d = self.__dict__                  # plain attributes: nn.Module.__setattr__ is slow on this path

@@ -176,6 +176,13 @@ def _install_cpu_stand_ins():
 
     ops.gate_logits, ops.routing_top2, ops.gather_rows = gate_logits, routing_top2, gather_rows
     ops.expert_ffn, ops.combine = expert_ffn, combine
+    def block_top2(x, wg, cap, noise, seed, drop, act, w1, b1, w2, b2, n_gated=-1):
+        lg = gate_logits(x, wg)
+        r = routing_top2(lg, cap, noise, drop)
+        y = expert_ffn(act, x, r.perm, 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows)
+        return combine(y, r, x.shape[0], x.shape[1]), lg, r
+
+    ops.block_top2 = block_top2
     ops.expert_ffn_routed = (lambda act, x, r, w1, b1, w2, b2, timer=None, n_gated=-1:
                              expert_ffn(act, x, r.perm, r.top_k - 1, w1, b1, w2, b2, r.expert_offsets, r.max_rows))
     ops.expert_ffn_train, ops.expert_ffn_bwd, ops.combine_bwd = expert_ffn_train, expert_ffn_bwd, combine_bwd
