@@ -26,6 +26,7 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--shape", default="both")
 ap.add_argument("--skew", type=int, default=1)
 ap.add_argument("--sorted", type=int, default=1, help="gather rows in token order (as the routing kernel produces them)")
+ap.add_argument("--cold", type=int, default=1, help="weight copies cycled per call (cold weights for decode-size runs)")
 ap.add_argument("--pad", type=int, default=0, help="pad leading dims of x / h (and the w buffers, for -DGEMM_EXP_LDW_PAD builds)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -34,8 +35,9 @@ M, I, E, R = a.M, a.I, a.E, a.rows
 S = R // 2
 P = a.pad
 x = torch.randn(S, M + P, device=dev).to(torch.bfloat16)
-w1 = (torch.randn(E, 2 * I + 8, M + P, device=dev) * 0.02).to(torch.bfloat16)
-w2 = (torch.randn(E, M + 8, I + P, device=dev) * 0.02).to(torch.bfloat16)
+w1s = [(torch.randn(E, 2 * I + 8, M + P, device=dev) * 0.02).to(torch.bfloat16) for _ in range(a.cold)]
+w2s = [(torch.randn(E, M + 8, I + P, device=dev) * 0.02).to(torch.bfloat16) for _ in range(a.cold)]
+calls = [0, 0]
 if a.skew:
     frac = torch.tensor([0.3026, 0.3103, 0.189, 0.198][:E]) if E == 4 else torch.ones(E) / E
 else:
@@ -49,17 +51,28 @@ st = torch.cuda.current_stream().cuda_stream
 libs = {v: load(v) for v in a.variants}
 
 def fc1(lib):
+    w1 = w1s[calls[0] % a.cold]; calls[0] += 1
     rc = lib.moe_grouped_gemm_fwd(1, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), None, offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, st)
     assert rc == 0, lib.moe_last_error()
 def fc2(lib):
+    w2 = w2s[calls[1] % a.cold]; calls[1] += 1
     rc = lib.moe_grouped_gemm_fwd(0, h.data_ptr(), I + P, None, 0, w2.data_ptr(), None, offs.data_ptr(), E, E, R, I, M, -1, y.data_ptr(), M, st)
     assert rc == 0, lib.moe_last_error()
 
 shapes = {"fc1": (fc1, 2.0 * R * 2 * I * M), "fc2": (fc2, 2.0 * R * M * I)}
 todo = ["fc1", "fc2"] if a.shape == "both" else [a.shape]
-for lib in libs.values():
+ref = None
+for v, lib in libs.items():
+    calls[0] = calls[1] = 0
+    h.zero_(); y.zero_()
     fc1(lib); fc2(lib)
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    cur = (h.clone(), y.clone())
+    if ref is None:
+        ref = cur
+    else:
+        print(f"{v}: outputs equal to {a.variants[0]}: h {bool(torch.equal(cur[0], ref[0]))} y {bool(torch.equal(cur[1], ref[1]))}", flush=True)
+del ref, cur
 res = {(v, s): [] for v in libs for s in todo}
 for r in range(a.rounds):
     for v, lib in libs.items():
