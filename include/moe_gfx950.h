@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 3
+#define MOE_ABI_VERSION 4
 
 /* activation / expert-MLP form of moe_expert_ffn_fwd */
 #define MOE_ACT_SWIGLU   0 /* h = silu(Wa x) * (Wb x); W1 = [Wa ; Wb] ([2I, M]).  StableLM: Wa=gate_proj, Wb=up_proj
@@ -84,6 +84,16 @@ int moe_routing_top2_fwd(const float *logits, const float *noise, uint64_t noise
                          int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
                          int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets,
                          int32_t *perm, float *l_aux, void *workspace, size_t ws_bytes, void *stream);
+
+/* moe_routing_top2_fwd_dseed: moe_routing_top2_fwd with the Gumbel seed kept in DEVICE memory.  The routing kernel
+ * reads *noise_seed_dev (0 = no noise) and replaces it with the next key of its stream, so the launch arguments do
+ * not change from call to call and a captured HIP graph of the step can be replayed (decode loops).  No counterpart
+ * upstream (gumbel_rsample draws from torch's generator on every call); single-launch sizes only: S <= 4096, E <= 16.
+ * noise_seed_dev: 8-byte aligned device pointer, read and written on `stream`. */
+int moe_routing_top2_fwd_dseed(const float *logits, uint64_t *noise_seed_dev, int S, int E, int capacity,
+                               int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
+                               int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets,
+                               int32_t *perm, float *l_aux, void *workspace, size_t ws_bytes, void *stream);
 
 /* moe_routing_top1_fwd: index form of upstream top1gating (MoE(k=1), reachable through
  * moellava/train/train.py:87-93 `top_k_experts` in {1,2}).
@@ -168,13 +178,23 @@ int moe_combine_fwd(const void *y, const int32_t *expert_idx, const int32_t *slo
  * moe_expert_ffn_fwd (rows gathered through perm, one group per expert, max_rows = min(2S, E*capacity) or 2S without
  * the drop) and moe_combine_fwd, in this order on `stream`, with exactly their argument meanings and buffers
  * (h_ws [max_rows, I], y [max_rows, M], out [S, M]).  Replaces MOELayer.forward for ep_size == 1;
- * a decode step's host cost is dominated by the number of calls, hence this one. */
+ * a decode step's host cost is dominated by the number of calls, hence this one.  For S <= 64 and E <= 8 the gate GEMV
+ * and the routing run as one launch (same arithmetic, bit-identical logits and routing). */
 int moe_block_top2_fwd(const void *x_bf16, const void *wg, int wg_is_bf16, float *logits, const float *noise,
                        uint64_t noise_seed, int S, int M, int E, int I, int act, int capacity, int drop_tokens,
                        int n_gated, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                        int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
                        void *routing_ws, size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2,
                        const void *b2, void *h_ws, void *y, void *out, void *stream);
+
+/* moe_block_top2_fwd_dseed: moe_block_top2_fwd with the routing of moe_routing_top2_fwd_dseed (seed in device memory,
+ * advanced by the kernel): the form a HIP graph of a decode step captures.  S <= 4096, E <= 16. */
+int moe_block_top2_fwd_dseed(const void *x_bf16, const void *wg, int wg_is_bf16, float *logits, uint64_t *noise_seed_dev,
+                             int S, int M, int E, int I, int act, int capacity, int drop_tokens, int n_gated,
+                             int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
+                             int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
+                             void *routing_ws, size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2,
+                             const void *b2, void *h_ws, void *y, void *out, void *stream);
 
 /* ---- backward ---------------------------------------------------------------
  * Upstream has no hand-written backward: torch autograd differentiates top2gating, the two einsums, _AllToAll

@@ -143,6 +143,11 @@ struct GemmParams {
 
 // Decode-size launches (moe_gemv.hip): every group has at most SKINNY_MAX_ROWS rows.
 constexpr int SKINNY_MAX_ROWS = 64;
+bool gate_route_small_applies(int S, int E);
+int launch_gate_route_small(const void *x, const void *wg, int wg_is_bf16, float *logits, const float *noise,
+                            uint64_t noise_seed, uint64_t *noise_seed_dev, int S, int M, int E, int capacity,
+                            int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
+                            int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux, void *stream);
 int launch_skinny_gemm(const GemmParams &p, int epilogue, hipStream_t st);
 
 // ---- helpers of the backward pass implemented in moe_backward.hip, used by moe_expert_ffn_bwd ----

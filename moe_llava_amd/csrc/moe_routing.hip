@@ -37,12 +37,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // gate GEMV: one wave computes R rows x E experts; lanes split M in 16-byte pieces of x.
 // Algorithmic bytes: S*M*2 (x) + E*M*4 (wg, L2-resident) + S*E*4 (logits).
 // ------------------------------------------------------------------------------------------------
+// rows row0 .. row0 + R - 1 (clamped to S - 1, stored only when < S) x E experts by ONE wave.  The result of a row
+// does not depend on R or on which wave computes it: a fixed per-lane fmaf chain over M, then the wave butterfly.
 template <int EMAX, int R, bool WG_BF16>
-__global__ __launch_bounds__(256) void gate_logits_kernel(const bf16_t *__restrict__ x, const void *__restrict__ wg,
-                                                          float *__restrict__ logits, int S, int M, int E) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + wave) * R;
-    if (row0 >= S) return;
+__device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const void *__restrict__ wg,
+                                          float *__restrict__ logits, int S, int M, int E, int row0, int lane) {
     float acc[R][EMAX];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -97,6 +96,15 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16_t *__restri
                 if (lane == 0 && row0 + r < S) logits[(size_t)(row0 + r) * E + e] = v;
             }
         }
+}
+
+template <int EMAX, int R, bool WG_BF16>
+__global__ __launch_bounds__(256) void gate_logits_kernel(const bf16_t *__restrict__ x, const void *__restrict__ wg,
+                                                          float *__restrict__ logits, int S, int M, int E) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + wave) * R;
+    if (row0 >= S) return;
+    gate_rows<EMAX, R, WG_BF16>(x, wg, logits, S, M, E, row0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -333,12 +341,15 @@ __global__ __launch_bounds__(RB) void route_finalize_kernel(int S, int E, int nb
 // ------------------------------------------------------------------------------------------------
 constexpr int FUSED_T = 4, FUSED_THREADS = 1024, FUSED_EMAX = 16;
 template <int EMAX>
-__global__ __launch_bounds__(FUSED_THREADS) void route_fused_kernel(
-    const float *__restrict__ logits, const float *__restrict__ noise, unsigned long long seed, int S, int E, int capacity,
-    int drop_tokens, int *__restrict__ expert_idx, int *__restrict__ slot, float *__restrict__ weight,
-    long long *__restrict__ exp_counts, int *__restrict__ kept_counts, int *__restrict__ expert_offsets,
-    int *__restrict__ perm, float *__restrict__ l_aux) {
+__device__ __forceinline__ void route_fused_body(
+    const float *logits, const float *__restrict__ noise, unsigned long long seed,
+    unsigned long long *seed_dev, int S, int E, int capacity, int drop_tokens, int *__restrict__ expert_idx,
+    int *__restrict__ slot, float *__restrict__ weight, long long *__restrict__ exp_counts, int *__restrict__ kept_counts,
+    int *__restrict__ expert_offsets, int *__restrict__ perm, float *__restrict__ l_aux) {
     constexpr int NW = FUSED_THREADS / 64;
+    // seed kept in device memory (HIP-graph replays: nothing on the host changes between launches): every thread
+    // reads it here, thread 0 replaces it after the first barrier below, when all reads are done
+    if (seed_dev) seed = *reinterpret_cast<volatile unsigned long long *>(seed_dev);
     __shared__ int wcnt[FUSED_T][2][NW][EMAX];   // counts, then exclusive bases (token order = chunk, wave)
     __shared__ float wsum[FUSED_T][NW][EMAX];
     __shared__ int s_n1[EMAX], s_off[EMAX + 1], s_cap;
@@ -375,6 +386,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void route_fused_kernel(
         }
     }
     __syncthreads();
+    if (seed_dev && tid == FUSED_THREADS - 1) {
+        unsigned long long nx = seed * 6364136223846793005ull + 1442695040888963407ull;  // next key of the Philox stream
+        *seed_dev = nx ? nx : 1ull;                                                          // 0 means "no noise"
+    }
     // exclusive scan over (chunk, wave) per (choice, expert); thread q = choice*E + e
     if (tid < 2 * E) {
         const int ch = tid / E, e = tid % E;
@@ -440,6 +455,34 @@ __global__ __launch_bounds__(FUSED_THREADS) void route_fused_kernel(
             }
         }
     }
+}
+
+template <int EMAX>
+__global__ __launch_bounds__(FUSED_THREADS) void route_fused_kernel(
+    const float *__restrict__ logits, const float *__restrict__ noise, unsigned long long seed,
+    unsigned long long *seed_dev, int S, int E, int capacity, int drop_tokens, int *__restrict__ expert_idx,
+    int *__restrict__ slot, float *__restrict__ weight, long long *__restrict__ exp_counts, int *__restrict__ kept_counts,
+    int *__restrict__ expert_offsets, int *__restrict__ perm, float *__restrict__ l_aux) {
+    route_fused_body<EMAX>(logits, noise, seed, seed_dev, S, E, capacity, drop_tokens, expert_idx, slot, weight, exp_counts,
+                           kept_counts, expert_offsets, perm, l_aux);
+}
+
+// Decode steps (S <= 64): gate GEMV and routing in ONE launch.  The 16 waves of the block compute 4 rows of logits each
+// (same arithmetic as gate_logits_kernel, so the logits are bit-identical), the logits go to global memory (they are an
+// output), and after the barrier the block routes them.
+constexpr int GATE_ROUTE_MAX_S = 64;
+template <int EMAX, bool WG_BF16>
+__global__ __launch_bounds__(FUSED_THREADS) void gate_route_fused_kernel(
+    const bf16_t *__restrict__ x, const void *__restrict__ wg, int M, float *logits, const float *__restrict__ noise,
+    unsigned long long seed, unsigned long long *seed_dev, int S, int E, int capacity, int drop_tokens,
+    int *__restrict__ expert_idx, int *__restrict__ slot, float *__restrict__ weight, long long *__restrict__ exp_counts,
+    int *__restrict__ kept_counts, int *__restrict__ expert_offsets, int *__restrict__ perm, float *__restrict__ l_aux) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave * 4 < S) gate_rows<EMAX, 4, WG_BF16>(x, wg, logits, S, M, E, wave * 4, lane);
+    __threadfence_block();
+    __syncthreads();  // the block's own global writes are visible to it after the barrier
+    route_fused_body<EMAX>(logits, noise, seed, seed_dev, S, E, capacity, drop_tokens, expert_idx, slot, weight, exp_counts,
+                           kept_counts, expert_offsets, perm, l_aux);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,10 +611,10 @@ extern "C" size_t moe_routing_workspace_bytes(int S, int E) {
     return carve(nullptr, S, E).total;
 }
 
-extern "C" int moe_routing_top2_fwd(const float *logits, const float *noise, uint64_t noise_seed, int S, int E,
-                                    int capacity, int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
-                                    int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm,
-                                    float *l_aux, void *workspace, size_t ws_bytes, void *stream) {
+static int routing_top2_launch(const float *logits, const float *noise, uint64_t noise_seed, uint64_t *noise_seed_dev, int S,
+                               int E, int capacity, int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
+                               int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm,
+                               float *l_aux, void *workspace, size_t ws_bytes, void *stream) {
     if (!logits || !expert_idx || !slot || !weight || !exp_counts || !kept_counts || !expert_offsets || !perm || !l_aux ||
         !workspace)
         return fail(MOE_ERR_ARG, "moe_routing_top2_fwd: null pointer");
@@ -588,15 +631,18 @@ extern "C" int moe_routing_top2_fwd(const float *logits, const float *noise, uin
     const unsigned long long seed = (unsigned long long)noise_seed;
     if (S <= FUSED_T * FUSED_THREADS && E <= FUSED_EMAX) {
 #define LAUNCH_FUSED(EM)                                                                                              \
-    hipLaunchKernelGGL((route_fused_kernel<EM>), dim3(1), dim3(FUSED_THREADS), 0, st, logits, noise, seed, S, E, capacity, \
-                       drop_tokens, expert_idx, slot, weight, (long long *)exp_counts, kept_counts, expert_offsets, perm,  \
-                       l_aux)
+    hipLaunchKernelGGL((route_fused_kernel<EM>), dim3(1), dim3(FUSED_THREADS), 0, st, logits, noise, seed,               \
+                       (unsigned long long *)noise_seed_dev, S, E, capacity, drop_tokens, expert_idx, slot, weight,        \
+                       (long long *)exp_counts, kept_counts, expert_offsets, perm, l_aux)
         if (E <= 4) LAUNCH_FUSED(4);
         else if (E <= 8) LAUNCH_FUSED(8);
         else LAUNCH_FUSED(16);
 #undef LAUNCH_FUSED
         return check_launch("route_fused_kernel");
     }
+    if (noise_seed_dev)
+        return fail(MOE_ERR_SHAPE, "moe_routing_top2_fwd_dseed: the device-side seed needs S <= %d and E <= %d (S=%d E=%d)",
+                    FUSED_T * FUSED_THREADS, FUSED_EMAX, S, E);
     const int nb = (S + RB - 1) / RB;
 #define LAUNCH_LOCAL(EM)                                                                                              \
     hipLaunchKernelGGL((route_local_kernel<EM>), dim3(nb), dim3(RB), 0, st, logits, noise, seed, S, E, nb, expert_idx, \
@@ -615,6 +661,55 @@ extern "C" int moe_routing_top2_fwd(const float *logits, const float *noise, uin
     hipLaunchKernelGGL(route_finalize_kernel, dim3(nb), dim3(RB), 0, st, S, E, nb, ws.hist, ws.meta, expert_offsets,
                        expert_idx, slot, weight, perm);
     return check_launch("route_finalize_kernel");
+}
+
+namespace moe {
+// gate + routing of a decode step in one launch (internal: moe_block_top2_fwd* use it when it applies)
+bool gate_route_small_applies(int S, int E) { return S >= 1 && S <= GATE_ROUTE_MAX_S && E >= 2 && E <= 8; }
+int launch_gate_route_small(const void *x, const void *wg, int wg_is_bf16, float *logits, const float *noise,
+                            uint64_t noise_seed, uint64_t *noise_seed_dev, int S, int M, int E, int capacity,
+                            int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
+                            int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux, void *stream) {
+    if (!x || !wg || !logits || !expert_idx || !slot || !weight || !exp_counts || !kept_counts || !expert_offsets || !perm ||
+        !l_aux)
+        return fail(MOE_ERR_ARG, "moe_block_top2_fwd: null pointer");
+    if (!gate_route_small_applies(S, E) || M <= 0 || (M & 7))
+        return fail(MOE_ERR_SHAPE, "moe_block_top2_fwd: need M%%8==0 (S=%d M=%d E=%d)", S, M, E);
+    if (drop_tokens && capacity < 0) return fail(MOE_ERR_SHAPE, "moe_block_top2_fwd: negative capacity");
+    if (noise && (noise_seed || noise_seed_dev))
+        return fail(MOE_ERR_ARG, "moe_block_top2_fwd: give a noise tensor or a seed, not both");
+    if (!aligned16(x) || !aligned16(wg) || ((uintptr_t)expert_idx & 7) || ((uintptr_t)slot & 7) || ((uintptr_t)weight & 7) ||
+        ((uintptr_t)noise_seed_dev & 7))
+        return fail(MOE_ERR_ALIGN, "moe_block_top2_fwd: x / wg need 16-byte, [S,2] arrays and the seed 8-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_GR(EM, BF)                                                                                                 \
+    hipLaunchKernelGGL((gate_route_fused_kernel<EM, BF>), dim3(1), dim3(FUSED_THREADS), 0, st, (const bf16_t *)x, wg, M,     \
+                       logits, noise, (unsigned long long)noise_seed, (unsigned long long *)noise_seed_dev, S, E, capacity,  \
+                       drop_tokens, expert_idx, slot, weight, (long long *)exp_counts, kept_counts, expert_offsets, perm,    \
+                       l_aux)
+    if (E <= 4) { if (wg_is_bf16) LAUNCH_GR(4, true); else LAUNCH_GR(4, false); }
+    else { if (wg_is_bf16) LAUNCH_GR(8, true); else LAUNCH_GR(8, false); }
+#undef LAUNCH_GR
+    return check_launch("gate_route_fused_kernel");
+}
+}  // namespace moe
+
+extern "C" int moe_routing_top2_fwd(const float *logits, const float *noise, uint64_t noise_seed, int S, int E,
+                                    int capacity, int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
+                                    int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm,
+                                    float *l_aux, void *workspace, size_t ws_bytes, void *stream) {
+    return routing_top2_launch(logits, noise, noise_seed, nullptr, S, E, capacity, drop_tokens, expert_idx, slot, weight,
+                               exp_counts, kept_counts, expert_offsets, perm, l_aux, workspace, ws_bytes, stream);
+}
+
+extern "C" int moe_routing_top2_fwd_dseed(const float *logits, uint64_t *noise_seed_dev, int S, int E, int capacity,
+                                          int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
+                                          int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm,
+                                          float *l_aux, void *workspace, size_t ws_bytes, void *stream) {
+    if (!noise_seed_dev || ((uintptr_t)noise_seed_dev & 7))
+        return fail(MOE_ERR_ARG, "moe_routing_top2_fwd_dseed: noise_seed_dev must be a non-null, 8-byte aligned device pointer");
+    return routing_top2_launch(logits, nullptr, 0, noise_seed_dev, S, E, capacity, drop_tokens, expert_idx, slot, weight,
+                               exp_counts, kept_counts, expert_offsets, perm, l_aux, workspace, ws_bytes, stream);
 }
 
 extern "C" int moe_gather_rows_fwd(const void *src, const int32_t *gather, int gather_shift, const int32_t *n_rows_dev,

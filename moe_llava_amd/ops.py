@@ -357,9 +357,11 @@ def expert_ffn_routed(act: int, x: Tensor, r: Routing, w1: Tensor, b1: Optional[
 
 
 def block_top2(x: Tensor, wg_weight: Tensor, capacity: int, noise: Optional[Tensor], noise_seed: int, drop_tokens: bool,
-               act: int, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], n_gated: int = -1):
+               act: int, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], n_gated: int = -1,
+               noise_seed_dev: Optional[Tensor] = None):
     """Whole block on one GPU in one library call (gate -> top-2 routing -> expert FFN -> combine).
-    Returns (out [S,M] bf16, logits [S,E] fp32, Routing)."""
+    Returns (out [S,M] bf16, logits [S,E] fp32, Routing).  ``noise_seed_dev`` (1-element int64 device tensor): the
+    Gumbel seed lives on the device and the routing kernel advances it -- the form a HIP graph can replay."""
     M, I, n_local = _check_ffn_weights(act, x, w1, b1, w2, b2)
     if wg_weight.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError(f"wg.weight: expected fp32 or bf16, got {wg_weight.dtype}")
@@ -382,6 +384,21 @@ def block_top2(x: Tensor, wg_weight: Tensor, capacity: int, noise: Optional[Tens
     hy = torch.empty((rows * (I + M),), dtype=torch.bfloat16, device=dev)   # h workspace, then y
     out = torch.empty((S, M), dtype=torch.bfloat16, device=dev)
     hp = hy.data_ptr()
+    if noise_seed_dev is not None:
+        _need(noise_seed_dev, "noise_seed_dev", torch.int64)
+        if noise is not None or noise_seed_dev.numel() != 1 or noise_seed_dev.device != dev:
+            raise ValueError("noise_seed_dev: one int64 on x's device, and no noise tensor with it")
+        with _on(dev):
+            rc = lib.moe_block_top2_fwd_dseed(
+                x.data_ptr(), wg_weight.data_ptr(), int(wg_weight.dtype == torch.bfloat16), logits.data_ptr(),
+                noise_seed_dev.data_ptr(), S, M, E, I, act,
+                int(capacity), int(bool(drop_tokens)), n_gated, r.ptr("expert_idx"), r.ptr("slot"), r.ptr("weight"),
+                r.ptr("exp_counts"), r.ptr("kept_counts"), r.ptr("expert_offsets"), r.ptr("perm"), r.ptr("l_aux"),
+                r.ptr("workspace"), ws_bytes, w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
+                b2.data_ptr() if b2 is not None else None, hp, hp + rows * I * 2, out.data_ptr(), _stream_ptr(x))
+        _lib.check(rc, "moe_block_top2_fwd_dseed")
+        r._keep = hy
+        return out, logits, r
     with _on(dev):
         rc = lib.moe_block_top2_fwd(
             x.data_ptr(), wg_weight.data_ptr(), int(wg_weight.dtype == torch.bfloat16), logits.data_ptr(),

@@ -237,8 +237,16 @@ class MOELayer(nn.Module):
             experts = self.experts
             act, w1, b1, w2, b2 = experts.packed(x.device)
             wgw = gate.wg.weight
-            cap, noise, seed = gate._top2_args(S, wgw.shape[0])
-            out, lg, r = ops.block_top2(x, wgw, cap, noise, seed, gate.drop_tokens, act, w1, b1, w2, b2, experts.n_gated)
+            seed_dev = gate.__dict__.get("noise_seed_dev")    # set by graph.GraphedMoE: seed lives on the device
+            if seed_dev is not None and gate.top2_2nd_expert_sampling and gate.noise_override is None:
+                cf = gate.capacity_factor if gate.training else gate.eval_capacity_factor
+                cap = capacity_of(S, wgw.shape[0], cf * 2, gate.min_capacity)
+                out, lg, r = ops.block_top2(x, wgw, cap, None, 0, gate.drop_tokens, act, w1, b1, w2, b2,
+                                            experts.n_gated, noise_seed_dev=seed_dev)
+            else:
+                cap, noise, seed = gate._top2_args(S, wgw.shape[0])
+                out, lg, r = ops.block_top2(x, wgw, cap, noise, seed, gate.drop_tokens, act, w1, b1, w2, b2,
+                                            experts.n_gated)
             gate.__dict__["last_logits"] = lg
             d = self.__dict__
             d["exp_counts"], d["last_routing"] = r.exp_counts, r

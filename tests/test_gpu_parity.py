@@ -477,3 +477,32 @@ def test_decode_sizes_skinny_kernel_vs_oracle_and_tiled(kind, M, I, E, S):
     err, scale = _report(f"decode {kind} S{S}", out.cpu(), r_out)
     assert torch.allclose(out.cpu().float(), r_out.float(), rtol=1e-2, atol=1e-2 * scale)
     assert torch.allclose(out.float(), out_tiled.float(), rtol=2e-2, atol=1e-2 * scale)
+
+
+@pytest.mark.parametrize("S,E,wg_bf16", [(1, 4, False), (5, 4, True), (33, 8, False), (64, 4, False), (64, 8, True)])
+def test_decode_gate_and_routing_in_one_launch_is_bit_identical(S, E, wg_bf16):
+    """For S <= 64 and E <= 8 the one-call block runs the gate GEMV and the routing as one launch: logits, routing and
+    output must equal the separate launches bit for bit (MOE_NO_GATE_ROUTE_FUSION=1 selects those)."""
+    import os
+    ops = _ops()
+    from moe_llava_amd import capacity_of
+    M, I = 256, 192
+    g = torch.Generator().manual_seed(S * 10 + E)
+    x = torch.randn(S, M, generator=g).to(torch.bfloat16).to(DEV)
+    wg = (torch.randn(E, M, generator=g) * 0.2).to(torch.bfloat16 if wg_bf16 else torch.float32).to(DEV)
+    w1 = (torch.randn(E, 2 * I, M, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    w2 = (torch.randn(E, M, I, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    cap = capacity_of(S, E, 2.0, 0)
+    seed = 4242 + S
+    out, lg, r = ops.block_top2(x, wg, cap, None, seed, True, 0, w1, None, w2, None)
+    os.environ["MOE_NO_GATE_ROUTE_FUSION"] = "1"
+    try:
+        out2, lg2, r2 = ops.block_top2(x, wg, cap, None, seed, True, 0, w1, None, w2, None)
+    finally:
+        del os.environ["MOE_NO_GATE_ROUTE_FUSION"]
+    torch.cuda.synchronize()
+    assert torch.equal(lg, ops.gate_logits(x, wg)) and torch.equal(lg, lg2)
+    for name in ("expert_idx", "slot", "weight", "exp_counts", "kept_counts", "expert_offsets", "l_aux"):
+        assert torch.equal(getattr(r, name), getattr(r2, name)), name
+    n = int(r.expert_offsets[-1])
+    assert torch.equal(r.perm[:n], r2.perm[:n]) and torch.equal(out, out2)

@@ -26,7 +26,7 @@ CONFIGS = {
 }
 
 
-def run(name, iters, warmup, n_layers):
+def run(name, iters, warmup, n_layers, graph=False):
     ctor, M, I, E, cf, S, training = CONFIGS[name]
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -52,6 +52,24 @@ def run(name, iters, warmup, n_layers):
         e1.record()
         torch.cuda.synchronize()
         total = e0.elapsed_time(e1) / iters
+        if graph:
+            from moe_llava_amd.graph import GraphedMoE
+            import time
+            gs = [GraphedMoE(m, x) for m in layers]
+            for i in range(n_layers):
+                gs[i](x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(iters * 4):
+                gs[i % n_layers](x)
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - t0) / (iters * 4)
+            t0 = time.perf_counter()
+            for i in range(iters * 4):
+                layers[i % n_layers](x)
+            torch.cuda.synchronize()
+            te = (time.perf_counter() - t0) / (iters * 4)
+            print(f"{name:24s} wall clock per step: eager {te*1e6:7.1f} us   HIP-graph replay {tg*1e6:7.1f} us", flush=True)
         t = ops.PhaseTimer()
         for m in layers:
             m.deepspeed_moe.timer = t
@@ -76,6 +94,7 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--layers", type=int, default=4, help="distinct weight sets cycled (cold weights)")
+    ap.add_argument("--graph", action="store_true", help="also time HIP-graph replays of the step (decode configs)")
     a = ap.parse_args()
     for c in a.configs:
-        run(c, a.iters, a.warmup, a.layers)
+        run(c, a.iters, a.warmup, a.layers, a.graph)
