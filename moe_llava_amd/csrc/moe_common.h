@@ -148,7 +148,7 @@ int launch_gate_route_small(const void *x, const void *wg, int wg_is_bf16, float
                             uint64_t noise_seed, uint64_t *noise_seed_dev, int S, int M, int E, int capacity,
                             int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                             int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux, void *stream);
-int launch_skinny_gemm(const GemmParams &p, int epilogue, hipStream_t st);
+int launch_skinny_gemm(const GemmParams &p, int epilogue, int max_rows, hipStream_t st);
 
 // ---- helpers of the backward pass implemented in moe_backward.hip, used by moe_expert_ffn_bwd ----
 // dst[b, c, r] = src[b, r, c]

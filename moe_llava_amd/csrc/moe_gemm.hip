@@ -511,7 +511,7 @@ static int grouped_gemm_launch(const char *fn, int epilogue, const void *a, int6
     p.bias_expert_stride = (epilogue == MOE_EPI_SWIGLU ? 2ll : 1ll) * N;
     // decode steps (at most 64 compact rows in the whole launch): weight-streaming GEMV-style kernel, no LDS tiles
     if (max_rows <= SKINNY_MAX_ROWS && epilogue <= MOE_EPI_GELU_NEW && !getenv("MOE_NO_SKINNY"))
-        return launch_skinny_gemm(p, epilogue, st);
+        return launch_skinny_gemm(p, epilogue, max_rows, st);
     const TileChoice t = choose_tile(epilogue, max_rows, G, N);
     if (epilogue == MOE_EPI_SWIGLU) return launch_gemm<EPI_SWIGLU>(p, max_rows, t, st);
     switch (epilogue) {

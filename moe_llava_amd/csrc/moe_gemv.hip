@@ -24,19 +24,21 @@ __device__ __forceinline__ bf16x8_t ld16(const bf16_t *p) {
 // NW = 16-column groups per block: one X fragment load serves NW (x2 when gated) weight fragments.
 // Measured (rocprofv3, S = 32, StableLM block, cold weights): the gated fc1 is fastest with 2 column groups per block
 // and K split in 2 (41 us; 47 us with 1 group), the plain fc2 (few columns, long K) with 1 group, 8 K steps in flight
-// and K split in 8 (31 us; 36-38 us with 4 groups).
-template <int EPI>
+// and K split in 8 (31 us; 36-38 us with 4 groups) -- and faster still with 2 groups and 4 K steps in flight when the
+// launch keeps >= 256 blocks (27 us): the host picks 1 or 2 groups per block for the plain epilogues.
+template <int EPI, int NWP>
 struct SkinnyCfg {
     static constexpr bool GATED = (EPI == EPI_SWIGLU);
     static constexpr int NACC = GATED ? 2 : 1;
-    static constexpr int NW = GATED ? 2 : 1;        // 16-column groups per block
-    static constexpr int U = GATED ? 2 : 8;         // K steps in flight: 8 weight loads (8 KiB per wave) either way
+    static constexpr int NW = NWP;                  // 16-column groups per block
+    static constexpr int U = 8 / (NACC * NW);       // K steps in flight: 8 weight loads (8 KiB per wave) either way
     static constexpr int COLS = 16 * NW;            // output columns per block
+    static_assert(NW == 1 || NW == 2, "column groups per block");
 };
 
-template <int EPI, int RT, int KSPLIT>
+template <int EPI, int RT, int KSPLIT, int NWP>
 __device__ __forceinline__ void skinny_body(const GemmParams &p, int grp, int row_begin, int n_rows, int ctile, float *red) {
-    using C = SkinnyCfg<EPI>;
+    using C = SkinnyCfg<EPI, NWP>;
     constexpr bool GATED = C::GATED;
     constexpr int NACC = C::NACC, NW = C::NW, U = C::U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,9 +162,9 @@ __device__ __forceinline__ void skinny_body(const GemmParams &p, int grp, int ro
     }
 }
 
-template <int EPI, int KSPLIT>
+template <int EPI, int KSPLIT, int NWP>
 __global__ __launch_bounds__(64 * KSPLIT) void skinny_gemm_kernel(const GemmParams p) {
-    using C = SkinnyCfg<EPI>;
+    using C = SkinnyCfg<EPI, NWP>;
     __shared__ __attribute__((aligned(16))) float red[KSPLIT * C::NACC * C::NW * 64 * 4];  // KSPLIT x 4 KiB
     const int ctile = blockIdx.x % p.col_tiles;
     const int grp = blockIdx.x / p.col_tiles;
@@ -170,16 +172,29 @@ __global__ __launch_bounds__(64 * KSPLIT) void skinny_gemm_kernel(const GemmPara
     const int n = e - b;
     if (n <= 0) return;                      // idle expert: its weights are not read (uniform for the block)
     switch ((min(n, SKINNY_MAX_ROWS) + 15) >> 4) {
-        case 1: skinny_body<EPI, 1, KSPLIT>(p, grp, b, min(n, 16), ctile, red); break;
-        case 2: skinny_body<EPI, 2, KSPLIT>(p, grp, b, min(n, 32), ctile, red); break;
-        case 3: skinny_body<EPI, 3, KSPLIT>(p, grp, b, min(n, 48), ctile, red); break;
-        default: skinny_body<EPI, 4, KSPLIT>(p, grp, b, min(n, 64), ctile, red); break;
+        case 1: skinny_body<EPI, 1, KSPLIT, NWP>(p, grp, b, min(n, 16), ctile, red); break;
+        case 2: skinny_body<EPI, 2, KSPLIT, NWP>(p, grp, b, min(n, 32), ctile, red); break;
+        case 3: skinny_body<EPI, 3, KSPLIT, NWP>(p, grp, b, min(n, 48), ctile, red); break;
+        default: skinny_body<EPI, 4, KSPLIT, NWP>(p, grp, b, min(n, 64), ctile, red); break;
     }
 }
 
-int launch_skinny_gemm(const GemmParams &p0, int epilogue, hipStream_t st) {
+int launch_skinny_gemm(const GemmParams &p0, int epilogue, int max_rows, hipStream_t st) {
     GemmParams p = p0;
-    const int cols = epilogue == MOE_EPI_SWIGLU ? SkinnyCfg<EPI_SWIGLU>::COLS : SkinnyCfg<EPI_PLAIN>::COLS;
+    const bool gated = epilogue == MOE_EPI_SWIGLU;
+    // Column groups per block.  Gated fc1: 2 (measured best).  Plain (fc2: few columns, long K): every 16-column block
+    // re-reads the group's X rows from L2, so 2 groups per block halve that traffic (S = 32: 31 -> 27 us) -- but only
+    // while the launch still has a block for every CU (S = 1, two active experts: 10.5 us with 1 group, 16 with 2).
+    int nw = 2;
+    if (!gated) {
+        const long long active = p.G < max_rows ? p.G : max_rows;  // groups that can hold rows
+        nw = active * ((p.N_out + 31) / 32) >= 256 ? 2 : 1;
+        if (const char *env = getenv("MOE_SKINNY_NW")) {  // tuning knob
+            const int v = atoi(env);
+            if (v == 1 || v == 2) nw = v;
+        }
+    }
+    const int cols = 16 * nw;
     p.col_tiles = (p.N_out + cols - 1) / cols;
     const long long grid = (long long)p.G * p.col_tiles;
     if (grid <= 0) return 0;
@@ -187,24 +202,27 @@ int launch_skinny_gemm(const GemmParams &p0, int epilogue, hipStream_t st) {
     // K split over the waves of a block so that the launch has ~16 wave-tasks per CU (enough loads in flight to cover
     // the HBM latency) but not more than one round of resident waves (a second, partial round would double the time)
     int ks = 8;
-    while (ks > 1 && grid * ks > (epilogue == MOE_EPI_SWIGLU ? 2048 : 4096)) ks >>= 1;
+    while (ks > 1 && grid * ks > (gated ? 2048 : 4096)) ks >>= 1;
     if (const char *env = getenv("MOE_SKINNY_KS")) {  // tuning knob: force the K split (1, 2, 4, 8)
         const int v = atoi(env);
         if (v == 1 || v == 2 || v == 4 || v == 8) ks = v;
     }
     const dim3 g((unsigned)grid), b(64 * ks);
-#define LAUNCH_SK(E_, K_) hipLaunchKernelGGL((skinny_gemm_kernel<E_, K_>), g, b, 0, st, p)
-#define LAUNCH_SK_ALL(E_)                                  \
+#define LAUNCH_SK(E_, K_, N_) hipLaunchKernelGGL((skinny_gemm_kernel<E_, K_, N_>), g, b, 0, st, p)
+#define LAUNCH_SK_KS(E_, N_)                               \
     switch (ks) {                                          \
-        case 8: LAUNCH_SK(E_, 8); break;                   \
-        case 4: LAUNCH_SK(E_, 4); break;                   \
-        case 2: LAUNCH_SK(E_, 2); break;                   \
-        default: LAUNCH_SK(E_, 1); break;                  \
+        case 8: LAUNCH_SK(E_, 8, N_); break;               \
+        case 4: LAUNCH_SK(E_, 4, N_); break;               \
+        case 2: LAUNCH_SK(E_, 2, N_); break;               \
+        default: LAUNCH_SK(E_, 1, N_); break;              \
     }
-    if (epilogue == MOE_EPI_SWIGLU) { LAUNCH_SK_ALL(EPI_SWIGLU) }
+#define LAUNCH_SK_ALL(E_)                                  \
+    if (nw == 2) { LAUNCH_SK_KS(E_, 2) } else { LAUNCH_SK_KS(E_, 1) }
+    if (gated) { LAUNCH_SK_KS(EPI_SWIGLU, 2) }
     else if (epilogue == MOE_EPI_GELU_NEW) { LAUNCH_SK_ALL(EPI_GELU_NEW) }
     else { LAUNCH_SK_ALL(EPI_PLAIN) }
 #undef LAUNCH_SK_ALL
+#undef LAUNCH_SK_KS
 #undef LAUNCH_SK
     return check_launch("skinny_gemm_kernel");
 }

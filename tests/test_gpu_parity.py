@@ -468,7 +468,16 @@ def test_decode_sizes_skinny_kernel_vs_oracle_and_tiled(kind, M, I, E, S):
             out_tiled, _, _ = mine(x.to(DEV))
         finally:
             del os.environ["MOE_NO_SKINNY"]
+        # the fc2 launch picks 1 or 2 column groups per block from the launch size; both give the same bits
+        forced = []
+        for nw in ("1", "2"):
+            os.environ["MOE_SKINNY_NW"] = nw
+            try:
+                forced.append(mine(x.to(DEV))[0])
+            finally:
+                del os.environ["MOE_SKINNY_NW"]
     torch.cuda.synchronize()
+    assert torch.equal(forced[0], forced[1]) and torch.equal(forced[0], out)
     assert mine.deepspeed_moe.last_routing.max_rows <= 64
     ref.deepspeed_moe.gate.logits_override = mine.deepspeed_moe.gate.last_logits.cpu()
     with torch.no_grad():
