@@ -323,7 +323,7 @@ def run(rank: int, world: int, port: int, mode: str, kind: str, result_dir: str)
                 ref_mod = fe[q * el + le]
                 for (n, p_ref) in ref_mod.named_parameters():
                     tot = p_ref.grad.detach().float().cpu().clone()
-                    dist.all_reduce(tot)
+                    dist.all_reduce(tot, group=part.deepspeed_moe.ep_group)   # the replicas of the shard inside ONE EP group
                     if q == ep_rank:
                         got = dict(mod.named_parameters())[n].grad.float().cpu()
                         scale = float(tot.abs().max())

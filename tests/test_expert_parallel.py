@@ -21,11 +21,11 @@ def _free_port():
     return p
 
 
-def _spawn(mode, kind):
+def _spawn(mode, kind, world=2):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(ep_worker.run, args=(2, _free_port(), mode, kind, d), nprocs=2, join=True)
+        mp.spawn(ep_worker.run, args=(world, _free_port(), mode, kind, d), nprocs=world, join=True)
         oks = sorted(os.listdir(d))
-        assert oks == ["ok_0", "ok_1"], oks
+        assert oks == [f"ok_{r}" for r in range(world)], oks
         return [open(os.path.join(d, f)).read() for f in oks]
 
 
@@ -33,6 +33,13 @@ def _spawn(mode, kind):
 def test_expert_parallel_exchange_cpu_gloo(kind):
     info = _spawn("cpu", kind)
     assert all("dropped=" in i for i in info)
+
+
+def test_expert_parallel_two_groups_of_two_cpu_gloo():
+    """world 4 = 2 expert-parallel groups x 2 ranks (the layout bench.py uses at N = 8: EP 4 x 2 replicas): every rank
+    creates every group, a rank's expert shard is rank % ep, the exchange stays inside its group."""
+    info = _spawn("cpu", "stablelm", world=4)
+    assert len(info) == 4
 
 
 @pytest.mark.gpu
