@@ -5,6 +5,8 @@ expert GEMM; the Python here only orchestrates launches (and, for ``ep_size > 1`
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Optional
 
@@ -399,15 +401,32 @@ def _expert_parallel_chunked(self, x, r, act, w1, b1, w2, b2, kept_h, me, C):
         works.append(w)
     y_cm = torch.empty((max(n_send, 1), M), dtype=torch.bfloat16, device=dev)   # returned rows, chunk-major
     back, keep = [], []
+    # The chunks' grouped FFNs alternate between the compute stream and a side stream: a chunk launch is only a few
+    # rounds of 256-row tiles (fc2: 1.4 rounds at the bench's shapes), and with two streams the next chunk's blocks
+    # fill the CUs that the tail of the previous launch leaves idle.
+    cur = torch.cuda.current_stream(dev) if x.is_cuda else None
+    two = cur is not None and C > 1 and os.environ.get("MOE_EP_STREAMS", "2") != "1"
+    if two:
+        side = self.__dict__.get("_side_stream")
+        if side is None or side.device != dev:
+            side = torch.cuda.Stream(device=dev)
+            self.__dict__["_side_stream"] = side
+        side.wait_stream(cur)                                  # the send buffer and the offsets are ready
     for c in range(C):
-        if works[c] is not None:
-            works[c].wait()
         rc, n_rc = recvs[c]
-        y_rc = ops.expert_ffn(act, rc, None, 0, w1, b1, w2, b2, offs_d[c], n_rc, timer=self.timer,
-                              n_gated=self.experts.n_gated)
-        keep.append(y_rc)
-        back.append(_all_to_all_rows_async(y_cm[send_edges[c]:send_edges[c + 1]], y_rc[:n_rc], send_cnt[:, c].tolist(),
-                                           recv_cnt[:, :, c].sum(1).tolist(), self.ep_group))
+        on_side = two and (c & 1)
+        with (torch.cuda.stream(side) if on_side else ops._NULL):
+            with (ops.stream_scope(rc) if two else ops._NULL):  # the launches follow the stream switch
+                if works[c] is not None:
+                    works[c].wait()
+                y_rc = ops.expert_ffn(act, rc, None, 0, w1, b1, w2, b2, offs_d[c], n_rc, timer=self.timer,
+                                      n_gated=self.experts.n_gated)
+                keep.append(y_rc)
+                back.append(_all_to_all_rows_async(y_cm[send_edges[c]:send_edges[c + 1]], y_rc[:n_rc],
+                                                   send_cnt[:, c].tolist(), recv_cnt[:, :, c].sum(1).tolist(),
+                                                   self.ep_group))
+    if two:
+        cur.wait_stream(side)
     for w in back:
         if w is not None:
             w.wait()
