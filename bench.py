@@ -73,7 +73,7 @@ def load_weights(moe, state, experts, device, ep_rank: int):
     return moe.to(device).train()
 
 
-def cpu_baseline(state, experts, budget_s: float = 12.0):
+def cpu_baseline(state, experts, budget_s: float = 12.0, gpu_moe=None, device=None):
     """Literal dense-mask restatement of the reference layer (oracle) on the host cores, one 704-token sample
     (BASELINE config 1: S=704, C=528).  Checker code timed as a reported baseline, never shipped."""
     from oracle import ds_moe_literal as lit
@@ -102,7 +102,46 @@ def cpu_baseline(state, experts, budget_s: float = 12.0):
     t = statistics.median(times)
     timed = times
     times = [None] + times                                   # (one warm-up run, not timed)
+    parity = None
+    if gpu_moe is not None:
+        # parity gates beside the perf number: the HIP block on the same 704-token sample against the
+        # oracle fed the kernel's fp32 logits and the same Gumbel noise
+        gate = gpu_moe.deepspeed_moe.gate
+        gate.noise_override = ref.deepspeed_moe.gate.noise.to(device)
+        try:
+            with torch.no_grad():
+                g_out, g_laux, g_cnt = gpu_moe(x.to(device))
+            torch.cuda.synchronize()
+            lg = gate.last_logits.float().cpu()
+            r = gpu_moe.deepspeed_moe.last_routing
+            from oracle import ds_moe_index as ix
+            want = ix.route_top2(lg.clone(), r.capacity, ref.deepspeed_moe.gate.noise, True)
+            ref.deepspeed_moe.gate.logits_override = lg
+            with torch.no_grad():
+                r_out, r_laux, r_cnt = ref(x)
+            ref.deepspeed_moe.gate.logits_override = None
+            top2 = torch.topk(torch.softmax(lg, 1), 2, dim=1).values
+            d = (g_out.cpu().float() - r_out.float()).abs()
+            parity = {"sample": f"S={S}, C={r.capacity}, oracle fed the kernel's logits and the same noise",
+                      "routing_bit_exact": bool(torch.equal(r.expert_idx.cpu(), want["expert_idx"])
+                                                and torch.equal(r.slot.cpu(), want["slot"])
+                                                and torch.equal(g_cnt.cpu(), r_cnt)
+                                                and torch.equal(r.kept_counts.cpu(), want["kept_counts"])),
+                      "l_aux_abs_err": abs(float(g_laux) - float(r_laux)),
+                      "out_max_abs_err": float(d.max()), "out_ref_max_abs": float(r_out.float().abs().max()),
+                      "out_within_rtol_1e-2": bool(torch.allclose(g_out.cpu().float(), r_out.float(), rtol=1e-2,
+                                                                  atol=1e-2 * float(r_out.float().abs().max()))),
+                      "tie_sensitive_tokens": int(((top2[:, 0] - top2[:, 1]) < 1e-5).sum())}
+        finally:
+            gate.noise_override = None
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": S / t, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model, "parity": parity,
             "sample": f"literal dense-mask oracle (restated deepspeed MoE, torch CPU bf16), 1 x ({N_IMG}+{N_TXT}) tokens "
                       f"= BASELINE config 1 (S={S}, C=528; the dense [S,E,C] masks of the full 22528-token batch would "
                       f"take 6 GB), repeated for {sum(timed):.1f} s of CPU work: {len(timed)} timed run(s) after "
@@ -244,7 +283,7 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(state, experts)
+            cpu = cpu_baseline(state, experts, gpu_moe=moe.train(), device=device)
         ms = elapsed / args.steps * 1e3
         n_kept = float(r.expert_offsets[-1]) / S             # kept (token, expert) pairs per token on rank 0
         line = {
