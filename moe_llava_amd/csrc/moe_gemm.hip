@@ -33,6 +33,9 @@ constexpr int NTHREADS = 512;
 #ifndef GEMM_AUX
 #define GEMM_AUX 0
 #endif
+#ifndef GEMM_PIPE
+#define GEMM_PIPE 1  // software-pipelined fragment reads (0 = all reads of a k-step, one wait, then its MFMAs)
+#endif
 constexpr int RS = GEMM_RS;  // row tiles per super-row (L2 reuse of the W panel inside an XCD)
 
 __device__ __forceinline__ void glds16(const bf16_t *gsrc, bf16_t *lds_wave_base) {
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     // Waves 0..LW-1 issue the LDS-DMA.  In-kernel stamps: a 1-KiB piece is accepted every ~80 cycles, so issuing a
     // slice's 64 pieces from all 8 waves cost each wave 640-1500 cycles at the head of every step with its SIMD's
     // matrix pipe idle.  With LW = 4 (one loader per SIMD) the partner wave starts its MFMAs at once: +2..4 %.
-    constexpr int LW = GEMM_LOADER_WAVES;
+    constexpr int LW = (BM == 256 && BNW == 256) ? GEMM_LOADER_WAVES : 4;
     constexpr int NPX = BM / PR / LW;   // X pieces per loader wave and slice (>= 1: BM >= 32)
     constexpr int NPW = BNW / PR / LW;  // W pieces per loader wave and slice
     static_assert(NPX >= 1 && NPW >= 1, "tile too small for the loader split");
@@ -241,6 +244,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #endif
 #ifndef GEMM_ABLATE_NO_MFMA
         const bf16_t *lb = lds_e + (kt % NS) * T::SLOT_ELEMS;
+#if GEMM_PIPE
+        // Software-pipelined fragment reads: the W fragments of a k-step (NF) stay in registers, the X fragments stream
+        // through a window of PD + 1 (each feeds NF MFMAs), and the next k-step's W fragments are read under the last
+        // MFMAs of the current one -- so only the first 4 + 1 reads after the barrier are exposed, not 12 per k-step.
+        // Same MFMA operands in the same k order: bit-identical results; 212 instead of 244 VGPRs.  Measured (same-process
+        // A/B, config 2): fc1 1686 -> 1594 us (+5.8 %), fc2 886 -> 861 us (+3 %); reading 3 or 4 X fragments ahead, issuing
+        // the LDS-DMA after the first reads, or spreading it over the MFMA groups (-11 %) did not help.
+        {
+            constexpr int PD = GEMM_PIPE + 1;     // X fragments read ahead
+            constexpr int TT = KS * MF;           // (k-step, row fragment) pairs of this slice
+            bf16x8_t wf[2][NF], xf[TT];
+            auto ldw = [&](int ks, int nf) {
+                return *reinterpret_cast<const bf16x8_t *>(lb + w_off + nf * 16 * BK + koff[ks]);
+            };
+            auto ldx = [&](int t) {
+                return *reinterpret_cast<const bf16x8_t *>(lb + x_off + (t % MF) * 16 * BK + koff[t / MF]);
+            };
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) wf[0][nf] = ldw(0, nf);
+#pragma unroll
+            for (int t = 0; t < PD && t < TT; ++t) xf[t] = ldx(t);
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef GEMM_NO_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const int ks = t / MF, mf = t % MF;
+                if (t + PD < TT) xf[t + PD] = ldx(t + PD);
+                if (ks + 1 < KS) {
+                    // next k-step's W fragments, spread over the last row fragments of this one
+                    if (MF >= NF) {
+                        if (mf >= MF - NF) wf[(ks + 1) & 1][mf - (MF - NF)] = ldw(ks + 1, mf - (MF - NF));
+                    } else if (mf == MF - 1) {
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf) wf[(ks + 1) & 1][nf] = ldw(ks + 1, nf);
+                    }
+                }
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nf], xf[t], acc[nf][mf], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifndef GEMM_NO_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             bf16x8_t xf[MF], wf[NF];
@@ -263,6 +314,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             __builtin_amdgcn_s_setprio(0);
 #endif
         }
+#endif
 #endif
 #ifdef GEMM_STAMPS
         const unsigned long long st_t3 = stamp();

@@ -20,6 +20,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
+#ifndef WG_PIPE
+#define WG_PIPE 1
+#endif
 constexpr int WT = 256;   // tile edge (both output dims)
 constexpr int WBK = 64;   // k rows per slice
 constexpr int WTHREADS = 512;
@@ -187,6 +190,35 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
                 __syncthreads();
             }
 #ifndef WG_NO_MFMA
+#if WG_PIPE
+            // software-pipelined fragment reads, as in moe_gemm.hip: the 4 B fragments of a k-step stay in registers, the
+            // 8 A fragments stream through a window of 3, the next k-step's B fragments are read under the last MFMAs
+            {
+                constexpr int PD = 2, TT = 16;
+                bf16x8_t wf[2][4], xf[TT];
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) wf[0][nf] = tr8(lb, wb[nf]);
+#pragma unroll
+                for (int t = 0; t < PD; ++t) xf[t] = tr8(lb, xb[t & 7] + (t >> 3) * 32 * WT * 2);
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef WG_NO_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    const int ks = t >> 3, mf = t & 7;
+                    if (t + PD < TT) xf[t + PD] = tr8(lb, xb[(t + PD) & 7] + ((t + PD) >> 3) * 32 * WT * 2);
+                    if (ks == 0 && mf >= 4) wf[1][mf - 4] = tr8(lb, wb[mf - 4] + 32 * WT * 2);
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf)
+                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nf], xf[t], acc[nf][mf], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#ifndef WG_NO_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8_t xf[8], wf[4];
@@ -206,6 +238,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
                 __builtin_amdgcn_s_setprio(0);
 #endif
             }
+#endif
 #endif
         }
     }
