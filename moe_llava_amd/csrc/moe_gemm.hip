@@ -33,6 +33,15 @@ constexpr int NTHREADS = 512;
 #ifndef GEMM_AUX
 #define GEMM_AUX 0
 #endif
+#ifndef GEMM_NT_STORE
+#define GEMM_NT_STORE 0
+#endif
+#ifndef GEMM_ASYM
+#define GEMM_ASYM 1     // 256 x 256 tile: loader waves own fewer row fragments than their SIMD partners
+#endif
+#ifndef GEMM_ASYM_MF
+#define GEMM_ASYM_MF 5  // row fragments (of 16) of a loader wave; its partner owns 16 - this
+#endif
 #ifndef GEMM_PIPE
 #define GEMM_PIPE 1  // software-pipelined fragment reads (0 = all reads of a k-step, one wait, then its MFMAs)
 #endif
@@ -45,6 +54,9 @@ __device__ __forceinline__ void glds16(const bf16_t *gsrc, bf16_t *lds_wave_base
             static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_wave_base))),
         16, 0, GEMM_AUX);
 }
+
+template <int N>
+struct IntC { static constexpr int value = N; };
 
 constexpr int EPI_PAD = 16;  // bytes of row padding in the output image
 
@@ -203,192 +215,209 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     int koff[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) koff[ks] = ((ks * 4 + fq) ^ xsw(fr)) * 8;
-    const int x_off = (wm * (BM / 2) + fr) * BK;
     const int w_off = BM * BK + (wn * WNT + fr) * BK;
-
-    f32x4_t acc[NF][MF];
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // K loop: ring of NS slots, NS-1 K slices of LDS-DMA in flight behind the one being consumed, one counted
-    // vmcnt + raw s_barrier per slice.  At step kt the slices issued behind kt are min(NS-2, nk-1-kt), PP LDS-DMA
-    // instructions per loader wave each.
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) stage(s, s);
 #ifdef GEMM_STAMPS
-    unsigned long long st_wait = 0, st_issue = 0, st_comp = 0, st_t0 = stamp(), st_begin = st_t0;
+    unsigned long long st_wait = 0, st_issue = 0, st_comp = 0, st_t0 = 0, st_begin = 0, st_loop_end = 0;
 #endif
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = nk - 1 - kt;
-        static_assert((NS - 2) * PP < 64, "vmcnt field");
-        switch (ahead < NS - 2 ? ahead : NS - 2) {
-            case 0: wait_vm_barrier<0>(); break;
-            case 1: wait_vm_barrier<PP>(); break;
-            case 2: wait_vm_barrier<(NS > 3 ? 2 : 0) * PP>(); break;
-            case 3: wait_vm_barrier<(NS > 4 ? 3 : 0) * PP>(); break;
-            case 4: wait_vm_barrier<(NS > 5 ? 4 : 0) * PP>(); break;
-            case 5: wait_vm_barrier<(NS > 6 ? 5 : 0) * PP>(); break;
-            default: wait_vm_barrier<(NS > 7 ? 6 : 0) * PP>(); break;
-        }
+
+    // K loop and register epilogue for a wave that owns MFW 16-row fragments starting at tile row row_off.  The two
+    // waves of a SIMD (wave w and w + 4) may own different shares: see ASYM below.
+    auto tile_body = [&](auto mfw_c, auto loads_c, const int row_off) {
+        constexpr int MFW = decltype(mfw_c)::value;
+        constexpr bool LOADS = decltype(loads_c)::value != 0;  // false: this wave never issues LDS-DMA (pointers dead)
+        const int x_off = (row_off + fr) * BK;
+
+        f32x4_t acc[NF][MFW];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MFW; ++mf) acc[nf][mf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        // K loop: ring of NS slots, NS-1 K slices of LDS-DMA in flight behind the one being consumed, one counted
+        // vmcnt + raw s_barrier per slice.  At step kt the slices issued behind kt are min(NS-2, nk-1-kt), PP LDS-DMA
+        // instructions per loader wave each.
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (LOADS && s < nk) stage(s, s);
 #ifdef GEMM_STAMPS
-        const unsigned long long st_t1 = stamp();
+        st_t0 = stamp(); st_begin = st_t0;
+#endif
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = nk - 1 - kt;
+            static_assert((NS - 2) * PP < 64, "vmcnt field");
+            switch (ahead < NS - 2 ? ahead : NS - 2) {
+                case 0: wait_vm_barrier<0>(); break;
+                case 1: wait_vm_barrier<PP>(); break;
+                case 2: wait_vm_barrier<(NS > 3 ? 2 : 0) * PP>(); break;
+                case 3: wait_vm_barrier<(NS > 4 ? 3 : 0) * PP>(); break;
+                case 4: wait_vm_barrier<(NS > 5 ? 4 : 0) * PP>(); break;
+                case 5: wait_vm_barrier<(NS > 6 ? 5 : 0) * PP>(); break;
+                default: wait_vm_barrier<(NS > 7 ? 6 : 0) * PP>(); break;
+            }
+#ifdef GEMM_STAMPS
+            const unsigned long long st_t1 = stamp();
 #endif
 #ifndef GEMM_ABLATE_NO_LOAD
-        if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
+            if (LOADS && kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
 #endif
 #ifdef GEMM_STAMPS
-        const unsigned long long st_t2 = stamp();
+            const unsigned long long st_t2 = stamp();
 #endif
 #ifndef GEMM_ABLATE_NO_MFMA
-        const bf16_t *lb = lds_e + (kt % NS) * T::SLOT_ELEMS;
+            const bf16_t *lb = lds_e + (kt % NS) * T::SLOT_ELEMS;
 #if GEMM_PIPE
-        // Software-pipelined fragment reads: the W fragments of a k-step (NF) stay in registers, the X fragments stream
-        // through a window of PD + 1 (each feeds NF MFMAs), and the next k-step's W fragments are read under the last
-        // MFMAs of the current one -- so only the first 4 + 1 reads after the barrier are exposed, not 12 per k-step.
-        // Same MFMA operands in the same k order: bit-identical results; 212 instead of 244 VGPRs.  Measured (same-process
-        // A/B, config 2): fc1 1686 -> 1594 us (+5.8 %), fc2 886 -> 861 us (+3 %); reading 3 or 4 X fragments ahead, issuing
-        // the LDS-DMA after the first reads, or spreading it over the MFMA groups (-11 %) did not help.
-        {
-            constexpr int PD = GEMM_PIPE + 1;     // X fragments read ahead
-            constexpr int TT = KS * MF;           // (k-step, row fragment) pairs of this slice
-            bf16x8_t wf[2][NF], xf[TT];
-            auto ldw = [&](int ks, int nf) {
-                return *reinterpret_cast<const bf16x8_t *>(lb + w_off + nf * 16 * BK + koff[ks]);
-            };
-            auto ldx = [&](int t) {
-                return *reinterpret_cast<const bf16x8_t *>(lb + x_off + (t % MF) * 16 * BK + koff[t / MF]);
-            };
+            // Software-pipelined fragment reads: the W fragments of a k-step (NF) stay in registers, the X fragments stream
+            // through a window of PD + 1 (each feeds NF MFMAs), and the next k-step's W fragments are read under the last
+            // MFMAs of the current one -- so only the first 4 + 1 reads after the barrier are exposed, not 12 per k-step.
+            // Same MFMA operands in the same k order: bit-identical results; 212 instead of 244 VGPRs.  Measured (same-process
+            // A/B, config 2): fc1 1686 -> 1594 us (+5.8 %), fc2 886 -> 861 us (+3 %); reading 3 or 4 X fragments ahead, issuing
+            // the LDS-DMA after the first reads, or spreading it over the MFMA groups (-11 %) did not help.
+            {
+                constexpr int PD = GEMM_PIPE + 1;     // X fragments read ahead
+                constexpr int TT = KS * MFW;           // (k-step, row fragment) pairs of this slice
+                bf16x8_t wf[2][NF], xf[TT];
+                auto ldw = [&](int ks, int nf) {
+                    return *reinterpret_cast<const bf16x8_t *>(lb + w_off + nf * 16 * BK + koff[ks]);
+                };
+                auto ldx = [&](int t) {
+                    return *reinterpret_cast<const bf16x8_t *>(lb + x_off + (t % MFW) * 16 * BK + koff[t / MFW]);
+                };
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf) wf[0][nf] = ldw(0, nf);
+                for (int nf = 0; nf < NF; ++nf) wf[0][nf] = ldw(0, nf);
 #pragma unroll
-            for (int t = 0; t < PD && t < TT; ++t) xf[t] = ldx(t);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < PD && t < TT; ++t) xf[t] = ldx(t);
+                __builtin_amdgcn_sched_barrier(0);
 #ifndef GEMM_NO_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-            for (int t = 0; t < TT; ++t) {
-                const int ks = t / MF, mf = t % MF;
-                if (t + PD < TT) xf[t + PD] = ldx(t + PD);
-                if (ks + 1 < KS) {
-                    // next k-step's W fragments, spread over the last row fragments of this one
-                    if (MF >= NF) {
-                        if (mf >= MF - NF) wf[(ks + 1) & 1][mf - (MF - NF)] = ldw(ks + 1, mf - (MF - NF));
-                    } else if (mf == MF - 1) {
+                for (int t = 0; t < TT; ++t) {
+                    const int ks = t / MFW, mf = t % MFW;
+                    if (t + PD < TT) xf[t + PD] = ldx(t + PD);
+                    if (ks + 1 < KS) {
+                        // next k-step's W fragments, spread over the last row fragments of this one
+                        if (MFW >= NF) {
+                            if (mf >= MFW - NF) wf[(ks + 1) & 1][mf - (MFW - NF)] = ldw(ks + 1, mf - (MFW - NF));
+                        } else if (mf == MFW - 1) {
 #pragma unroll
-                        for (int nf = 0; nf < NF; ++nf) wf[(ks + 1) & 1][nf] = ldw(ks + 1, nf);
+                            for (int nf = 0; nf < NF; ++nf) wf[(ks + 1) & 1][nf] = ldw(ks + 1, nf);
+                        }
+                    }
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf)
+                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nf], xf[t], acc[nf][mf], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#ifndef GEMM_NO_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+#else
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8_t xf[MFW], wf[NF];
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+                    wf[nf] = *reinterpret_cast<const bf16x8_t *>(lb + w_off + nf * 16 * BK + koff[ks]);
+#pragma unroll
+                for (int mf = 0; mf < MFW; ++mf)
+                    xf[mf] = *reinterpret_cast<const bf16x8_t *>(lb + x_off + mf * 16 * BK + koff[ks]);
+#ifndef GEMM_NO_SETPRIO
+                __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster together (+1..3 % measured)
+#endif
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+#pragma unroll
+                    for (int mf = 0; mf < MFW; ++mf)
+                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+                }
+#ifndef GEMM_NO_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+#endif
+#endif
+#ifdef GEMM_STAMPS
+            const unsigned long long st_t3 = stamp();
+            st_wait += st_t1 - st_t0; st_issue += st_t2 - st_t1; st_comp += st_t3 - st_t2; st_t0 = st_t3;
+#endif
+        }
+#ifdef GEMM_STAMPS
+        st_loop_end = stamp();
+#endif
+
+        // ---- epilogue: activation in registers -> bf16 tile image in LDS -> 16-byte, full-line global stores ----
+        const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
+        __syncthreads();  // every wave is done reading the ring
+        if (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int nf = 0; nf < NF / 2; ++nf) {
+                const int cl = wn * (WNT / 2) + nf * 16 + fq * 4;  // column inside the tile
+                const int c0 = ct * NC + cl;
+                float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias && c0 < p.N_out) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ba[j] = bf2f(bias[c0 + j]);
+                        bb[j] = bf2f(bias[p.b_row_offset + c0 + j]);
                     }
                 }
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf)
-                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nf], xf[t], acc[nf][mf], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int mf = 0; mf < MFW; ++mf) {
+                    unsigned short h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = rbf(acc[nf][mf][j] + ba[j]);            // bf16 output of the 'a' Linear
+                        const float b = rbf(acc[nf + NF / 2][mf][j] + bb[j]);   // bf16 output of the 'b' Linear
+                        // F.silu on a bf16 tensor; RePaMLP: torch.where(mask, silu, 1) (llava_stablelm_moe.py:636-638)
+                        const float sg = (c0 + j < p.n_gated) ? rbf(fast_silu(a)) : 1.0f;
+                        h[j] = f2bf(sg * b);
+                    }
+                    uint2 o;
+                    o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+                    o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+                    *reinterpret_cast<uint2 *>(lds + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
+                }
             }
-#ifndef GEMM_NO_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-        }
-#else
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8_t xf[MF], wf[NF];
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
-                wf[nf] = *reinterpret_cast<const bf16x8_t *>(lb + w_off + nf * 16 * BK + koff[ks]);
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-                xf[mf] = *reinterpret_cast<const bf16x8_t *>(lb + x_off + mf * 16 * BK + koff[ks]);
-#ifndef GEMM_NO_SETPRIO
-            __builtin_amdgcn_s_setprio(1);  // keeps the MFMA cluster together (+1..3 % measured)
-#endif
+        } else {
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
+                const int cl = wn * WNT + nf * 16 + fq * 4;
+                const int c0 = ct * NC + cl;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias && c0 < p.N_out) {
 #pragma unroll
-                for (int mf = 0; mf < MF; ++mf)
-                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
-            }
-#ifndef GEMM_NO_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-        }
-#endif
-#endif
-#ifdef GEMM_STAMPS
-        const unsigned long long st_t3 = stamp();
-        st_wait += st_t1 - st_t0; st_issue += st_t2 - st_t1; st_comp += st_t3 - st_t2; st_t0 = st_t3;
-#endif
-    }
-#ifdef GEMM_STAMPS
-    const unsigned long long st_loop_end = stamp();
-#endif
-#ifdef GEMM_ABLATE_NO_STORE
+                    for (int j = 0; j < 4; ++j) bv[j] = bf2f(bias[c0 + j]);
+                }
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
+                for (int mf = 0; mf < MFW; ++mf) {
+                    unsigned short h[4];
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) asm volatile("" ::"v"(acc[nf][mf]));
-    return;
-#endif
-
-    // ---- epilogue: activation in registers -> bf16 tile image in LDS -> 16-byte, full-line global stores ----
-    const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
-    __syncthreads();  // every wave is done reading the ring
-    if (EPI == EPI_SWIGLU) {
-#pragma unroll
-        for (int nf = 0; nf < NF / 2; ++nf) {
-            const int cl = wn * (WNT / 2) + nf * 16 + fq * 4;  // column inside the tile
-            const int c0 = ct * NC + cl;
-            float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias && c0 < p.N_out) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ba[j] = bf2f(bias[c0 + j]);
-                    bb[j] = bf2f(bias[p.b_row_offset + c0 + j]);
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = rbf(acc[nf][mf][j] + bv[j]);  // bf16 output of the Linear
+                        h[j] = (EPI == EPI_GELU_NEW) ? f2bf(gelu_new_bf16(v)) : f2bf(v);
+                    }
+                    uint2 o;
+                    o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+                    o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+                    *reinterpret_cast<uint2 *>(lds + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
                 }
             }
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) {
-                unsigned short h[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = rbf(acc[nf][mf][j] + ba[j]);            // bf16 output of the 'a' Linear
-                    const float b = rbf(acc[nf + NF / 2][mf][j] + bb[j]);   // bf16 output of the 'b' Linear
-                    // F.silu on a bf16 tensor; RePaMLP: torch.where(mask, silu, 1) (llava_stablelm_moe.py:636-638)
-                    const float sg = (c0 + j < p.n_gated) ? rbf(fast_silu(a)) : 1.0f;
-                    h[j] = f2bf(sg * b);
-                }
-                uint2 o;
-                o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-                o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-                *reinterpret_cast<uint2 *>(lds + (wm * (BM / 2) + mf * 16 + fr) * ROWB + cl * 2) = o;
-            }
         }
+    };
+    // ASYM (256 x 256 tile): the loader waves (0-3, rows 0..79) own 5 row fragments, their SIMD partners (4-7, rows
+    // 80..255) own 11.  A loader wave is blocked ~1000-1400 cycles per slice issuing the LDS-DMA before it can start its
+    // MFMAs, while its partner computes and then waits at the barrier; shifting MFMA work to the partner shortens the
+    // loader's chain (issue + compute), which is what sets the length of a K step.  The partner's body has no LDS-DMA
+    // code, so the staging pointers are dead there and 176 accumulator registers fit (244 VGPRs, no spill).  Same
+    // MFMA operands per output element: bit-identical.  Measured (same-process A/B, config 2): fc2 862 -> 814 us
+    // (+5.9 %), fc1 1622 -> 1593 us (+1.8 %); splits 4/12, 6/10, 7/9 are within 1.5 % of 5/11.
+    constexpr bool ASYM = GEMM_ASYM && BM == 256 && BNW == 256 && LW == 4;
+    if (ASYM) {
+        if (__builtin_amdgcn_readfirstlane(wave) < 4) tile_body(IntC<GEMM_ASYM_MF>{}, IntC<1>{}, 0);
+        else tile_body(IntC<16 - GEMM_ASYM_MF>{}, IntC<0>{}, GEMM_ASYM_MF * 16);
     } else {
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-            const int cl = wn * WNT + nf * 16 + fq * 4;
-            const int c0 = ct * NC + cl;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias && c0 < p.N_out) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = bf2f(bias[c0 + j]);
-            }
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) {
-                unsigned short h[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = rbf(acc[nf][mf][j] + bv[j]);  // bf16 output of the Linear
-                    h[j] = (EPI == EPI_GELU_NEW) ? f2bf(gelu_new_bf16(v)) : f2bf(v);
-                }
-                uint2 o;
-                o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-                o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-                *reinterpret_cast<uint2 *>(lds + (wm * (BM / 2) + mf * 16 + fr) * ROWB + cl * 2) = o;
-            }
-        }
+        tile_body(IntC<MF>{}, IntC<1>{}, wm * (BM / 2));
     }
     __syncthreads();
     {
@@ -421,7 +450,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                         *reinterpret_cast<uint4 *>(dst) = pack8(dx);
                     }
                 } else if (ncols_ok >= 8) {
+#if GEMM_NT_STORE
+                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                    u32x4_t vv = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_t *>(dst));
+#else
                     *reinterpret_cast<uint4 *>(dst) = v;
+#endif
                 } else {
                     *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
                 }
