@@ -23,6 +23,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #ifndef WG_PIPE
 #define WG_PIPE 1
 #endif
+#ifndef WG_ASYM
+#define WG_ASYM 1
+#endif
+#ifndef WG_ASYM_MF
+#define WG_ASYM_MF 5
+#endif
+template <int N>
+struct WIntC { static constexpr int value = N; };
 constexpr int WT = 256;   // tile edge (both output dims)
 constexpr int WBK = 64;   // k rows per slice
 constexpr int WTHREADS = 512;
@@ -83,12 +91,6 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
 
-    f32x4_t acc[4][8];
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < 8; ++mf) acc[nf][mf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
     // ---- staging: piece q (0..31) of a tile = k rows 2q, 2q+1; lane -> k row 2q + (lane >> 5), LDS chunk lane & 31,
     //      which holds source chunk (lane & 31) ^ ksw(k).  Waves 0..3 issue 8 pieces of each operand per slice.
     //      For piece q = lwave*8 + j the key ksw(k) depends on j only through (j & 1) and (j >> 2): 4 column offsets. ----
@@ -116,10 +118,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
     //      base (bytes inside a slot) and the k steps are immediates: + ks*16384 + half*2048. ----
     const int tq = fr >> 2, tp = fr & 3;
     const int key = (tq | ((fq & 1) << 2)) << 1;
-    int xb[8], wb[4];
-#pragma unroll
-    for (int mf = 0; mf < 8; ++mf)
-        xb[mf] = (fq * 8 + tq) * (WT * 2) + (((wm * 16 + mf * 2 + (tp >> 1)) ^ key) << 4) + ((tp & 1) << 3);
+    int wb[4];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf)
         wb[nf] = WBK * WT * 2 + (fq * 8 + tq) * (WT * 2) + (((wn * 8 + nf * 2 + (tp >> 1)) ^ key) << 4) + ((tp & 1) << 3);
@@ -132,130 +131,153 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
         return __builtin_bit_cast(bf16x8_t, v);
     };
 
-    // the groups of this expert: e, e + El, ... ; each is a K range of its own (expert-parallel receive layout)
-    const int per = p.G / p.n_experts;
-    for (int src = 0; src < per; ++src) {
-        const int g = src * p.n_experts + expert;
-        const int k_first = p.group_offsets[g];
-        const int nrows = p.group_offsets[g + 1] - k_first;
-        const int nk = (nrows + WBK - 1) / WBK;
-        if (nk == 0) continue;
-        // Sources as uniform base + 32-bit lane offset (bytes): one v_add3 per piece in the steady state.  The last
-        // slice clamps its rows to the group's last row (in bounds) and the rows past the end are zeroed in LDS below.
-        const char *abase = reinterpret_cast<const char *>(p.a + (long long)k_first * p.lda);
-        const char *bbase = reinterpret_cast<const char *>(p.b + (long long)k_first * p.ldb);
-        const unsigned lda_b = (unsigned)p.lda * 2u, ldb_b = (unsigned)p.ldb * 2u;
-        auto stage = [&](int buf, int kt) {
-            if (!loader) return;
-            bf16_t *slot = reinterpret_cast<bf16_t *>(lds_b) + buf * W_SLOT_ELEMS + lwave * NPL * 512;
-            const unsigned row0 = (unsigned)(kt * WBK + lwave * NPL * 2 + kl);
-            if (kt + 1 < nk) {
-                const unsigned ra = row0 * lda_b, rb = row0 * ldb_b;
+    // K loop and register epilogue of a wave that owns MFW 16-row fragments (tile rows row_off ..) of the r dimension.
+    auto tile_body = [&](auto mfw_c, auto loads_c, const int row_off) {
+        constexpr int MFW = decltype(mfw_c)::value;
+        constexpr bool LOADS = decltype(loads_c)::value != 0;  // false: this wave never issues LDS-DMA
+        f32x4_t acc[4][MFW];
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    const int t = (j & 1) | ((((lwave * NPL + j) >> 2) & 1) << 1);
-                    glds16w(reinterpret_cast<const bf16_t *>(abase + (ra + (unsigned)(2 * j) * lda_b + (unsigned)a_col[t])),
-                            slot + j * 512);
-                    glds16w(reinterpret_cast<const bf16_t *>(bbase + (rb + (unsigned)(2 * j) * ldb_b + (unsigned)b_col[t])),
-                            slot + WBK * WT + j * 512);
-                }
-            } else {
+        for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    const int t = (j & 1) | ((((lwave * NPL + j) >> 2) & 1) << 1);
-                    const unsigned r = min(row0 + (unsigned)(2 * j), (unsigned)(nrows - 1));
-                    glds16w(reinterpret_cast<const bf16_t *>(abase + (r * lda_b + (unsigned)a_col[t])), slot + j * 512);
-                    glds16w(reinterpret_cast<const bf16_t *>(bbase + (r * ldb_b + (unsigned)b_col[t])),
-                            slot + WBK * WT + j * 512);
+            for (int mf = 0; mf < MFW; ++mf) acc[nf][mf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        int xb[MFW];
+#pragma unroll
+        for (int mf = 0; mf < MFW; ++mf)
+            xb[mf] = (fq * 8 + tq) * (WT * 2) + ((((row_off >> 3) + mf * 2 + (tp >> 1)) ^ key) << 4) + ((tp & 1) << 3);
+        // the groups of this expert: e, e + El, ... ; each is a K range of its own (expert-parallel receive layout)
+        const int per = p.G / p.n_experts;
+        for (int src = 0; src < per; ++src) {
+            const int g = src * p.n_experts + expert;
+            const int k_first = p.group_offsets[g];
+            const int nrows = p.group_offsets[g + 1] - k_first;
+            const int nk = (nrows + WBK - 1) / WBK;
+            if (nk == 0) continue;
+            // Sources as uniform base + 32-bit lane offset (bytes): one v_add3 per piece in the steady state.  The last
+            // slice clamps its rows to the group's last row (in bounds) and the rows past the end are zeroed in LDS below.
+            const char *abase = reinterpret_cast<const char *>(p.a + (long long)k_first * p.lda);
+            const char *bbase = reinterpret_cast<const char *>(p.b + (long long)k_first * p.ldb);
+            const unsigned lda_b = (unsigned)p.lda * 2u, ldb_b = (unsigned)p.ldb * 2u;
+            auto stage = [&](int buf, int kt) {
+                if (!LOADS || !loader) return;
+                bf16_t *slot = reinterpret_cast<bf16_t *>(lds_b) + buf * W_SLOT_ELEMS + lwave * NPL * 512;
+                const unsigned row0 = (unsigned)(kt * WBK + lwave * NPL * 2 + kl);
+                if (kt + 1 < nk) {
+                    const unsigned ra = row0 * lda_b, rb = row0 * ldb_b;
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) {
+                        const int t = (j & 1) | ((((lwave * NPL + j) >> 2) & 1) << 1);
+                        glds16w(reinterpret_cast<const bf16_t *>(abase + (ra + (unsigned)(2 * j) * lda_b + (unsigned)a_col[t])),
+                                slot + j * 512);
+                        glds16w(reinterpret_cast<const bf16_t *>(bbase + (rb + (unsigned)(2 * j) * ldb_b + (unsigned)b_col[t])),
+                                slot + WBK * WT + j * 512);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) {
+                        const int t = (j & 1) | ((((lwave * NPL + j) >> 2) & 1) << 1);
+                        const unsigned r = min(row0 + (unsigned)(2 * j), (unsigned)(nrows - 1));
+                        glds16w(reinterpret_cast<const bf16_t *>(abase + (r * lda_b + (unsigned)a_col[t])), slot + j * 512);
+                        glds16w(reinterpret_cast<const bf16_t *>(bbase + (r * ldb_b + (unsigned)b_col[t])),
+                                slot + WBK * WT + j * 512);
+                    }
                 }
-            }
-        };
-        __syncthreads();  // previous group's last slice is fully consumed before the ring is reused
-        stage(0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            wait_vm_barrier_w<0>();
+            };
+            __syncthreads();  // previous group's last slice is fully consumed before the ring is reused
+            stage(0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                wait_vm_barrier_w<0>();
 #ifndef WG_NO_LOAD
-            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+                if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
 #endif
-            const char *lb = lds_b + (kt & 1) * (W_SLOT_ELEMS * 2);
-            if (kt == nk - 1 && (nrows & (WBK - 1))) {
-                // zero the k rows past the group's end in both tiles (they hold a copy of the last row), then re-sync
-                const int rem = nrows & (WBK - 1);
-                char *wlb = lds_b + (kt & 1) * (W_SLOT_ELEMS * 2);
-                for (int i = tid; i < (WBK - rem) * 64; i += WTHREADS) {
-                    const int row = rem + (i >> 6), ch = i & 63;  // 64 chunks: 32 of the A tile row, 32 of the B tile row
-                    char *dst = wlb + (ch >> 5) * (WBK * WT * 2) + row * (WT * 2) + (ch & 31) * 16;
-                    *reinterpret_cast<uint4 *>(dst) = make_uint4(0u, 0u, 0u, 0u);
+                const char *lb = lds_b + (kt & 1) * (W_SLOT_ELEMS * 2);
+                if (kt == nk - 1 && (nrows & (WBK - 1))) {
+                    // zero the k rows past the group's end in both tiles (they hold a copy of the last row), then re-sync
+                    const int rem = nrows & (WBK - 1);
+                    char *wlb = lds_b + (kt & 1) * (W_SLOT_ELEMS * 2);
+                    for (int i = tid; i < (WBK - rem) * 64; i += WTHREADS) {
+                        const int row = rem + (i >> 6), ch = i & 63;  // 64 chunks: 32 of the A tile row, 32 of the B tile row
+                        char *dst = wlb + (ch >> 5) * (WBK * WT * 2) + row * (WT * 2) + (ch & 31) * 16;
+                        *reinterpret_cast<uint4 *>(dst) = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
-            }
 #ifndef WG_NO_MFMA
 #if WG_PIPE
-            // software-pipelined fragment reads, as in moe_gemm.hip: the 4 B fragments of a k-step stay in registers, the
-            // 8 A fragments stream through a window of 3, the next k-step's B fragments are read under the last MFMAs
-            {
-                constexpr int PD = 2, TT = 16;
-                bf16x8_t wf[2][4], xf[TT];
+                // software-pipelined fragment reads, as in moe_gemm.hip: the 4 B fragments of a k-step stay in registers, the
+                // A fragments stream through a window of 3, the next k-step's B fragments are read under the last MFMAs
+                {
+                    constexpr int PD = 2, TT = 2 * MFW;
+                    bf16x8_t wf[2][4], xf[TT];
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf) wf[0][nf] = tr8(lb, wb[nf]);
+                    for (int nf = 0; nf < 4; ++nf) wf[0][nf] = tr8(lb, wb[nf]);
 #pragma unroll
-                for (int t = 0; t < PD; ++t) xf[t] = tr8(lb, xb[t & 7] + (t >> 3) * 32 * WT * 2);
-                __builtin_amdgcn_sched_barrier(0);
-#ifndef WG_NO_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-                for (int t = 0; t < TT; ++t) {
-                    const int ks = t >> 3, mf = t & 7;
-                    if (t + PD < TT) xf[t + PD] = tr8(lb, xb[(t + PD) & 7] + ((t + PD) >> 3) * 32 * WT * 2);
-                    if (ks == 0 && mf >= 4) wf[1][mf - 4] = tr8(lb, wb[mf - 4] + 32 * WT * 2);
-#pragma unroll
-                    for (int nf = 0; nf < 4; ++nf)
-                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nf], xf[t], acc[nf][mf], 0, 0, 0);
+                    for (int t = 0; t < PD; ++t) xf[t] = tr8(lb, xb[t % MFW] + (t / MFW) * 32 * WT * 2);
                     __builtin_amdgcn_sched_barrier(0);
-                }
 #ifndef WG_NO_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_s_setprio(1);
 #endif
-            }
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        const int ks = t / MFW, mf = t % MFW;
+                        if (t + PD < TT) xf[t + PD] = tr8(lb, xb[(t + PD) % MFW] + ((t + PD) / MFW) * 32 * WT * 2);
+                        if (ks == 0 && mf >= MFW - 4) wf[1][mf - (MFW - 4)] = tr8(lb, wb[mf - (MFW - 4)] + 32 * WT * 2);
+#pragma unroll
+                        for (int nf = 0; nf < 4; ++nf)
+                            acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nf], xf[t], acc[nf][mf], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#ifndef WG_NO_SETPRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+                }
 #else
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t xf[8], wf[4];
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8_t xf[MFW], wf[4];
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf) wf[nf] = tr8(lb, wb[nf] + ks * 32 * WT * 2);
+                    for (int nf = 0; nf < 4; ++nf) wf[nf] = tr8(lb, wb[nf] + ks * 32 * WT * 2);
 #pragma unroll
-                for (int mf = 0; mf < 8; ++mf) xf[mf] = tr8(lb, xb[mf] + ks * 32 * WT * 2);
+                    for (int mf = 0; mf < MFW; ++mf) xf[mf] = tr8(lb, xb[mf] + ks * 32 * WT * 2);
 #ifndef WG_NO_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
+                    __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf)
+                    for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-                    for (int mf = 0; mf < 8; ++mf)
-                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+                        for (int mf = 0; mf < MFW; ++mf)
+                            acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
 #ifndef WG_NO_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+                }
+#endif
 #endif
             }
-#endif
-#endif
         }
-    }
 
-    // ---- epilogue: bf16 tile image in LDS -> 16-byte full-line stores ----
-    __syncthreads();
+        // ---- epilogue: bf16 tile image in LDS -> 16-byte full-line stores ----
+        __syncthreads();
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-        const int cl = wn * 64 + nf * 16 + fq * 4;
+        for (int nf = 0; nf < 4; ++nf) {
+            const int cl = wn * 64 + nf * 16 + fq * 4;
 #pragma unroll
-        for (int mf = 0; mf < 8; ++mf) {
-            uint2 o;
-            o.x = (unsigned)f2bf(acc[nf][mf][0]) | ((unsigned)f2bf(acc[nf][mf][1]) << 16);
-            o.y = (unsigned)f2bf(acc[nf][mf][2]) | ((unsigned)f2bf(acc[nf][mf][3]) << 16);
-            *reinterpret_cast<uint2 *>(lds + (wm * 128 + mf * 16 + fr) * W_EPI_ROWB + cl * 2) = o;
+            for (int mf = 0; mf < MFW; ++mf) {
+                uint2 o;
+                o.x = (unsigned)f2bf(acc[nf][mf][0]) | ((unsigned)f2bf(acc[nf][mf][1]) << 16);
+                o.y = (unsigned)f2bf(acc[nf][mf][2]) | ((unsigned)f2bf(acc[nf][mf][3]) << 16);
+                *reinterpret_cast<uint2 *>(lds + (row_off + mf * 16 + fr) * W_EPI_ROWB + cl * 2) = o;
+            }
         }
-    }
+    };
+    // Asymmetric split as in moe_gemm.hip: the loader waves (0-3) own WG_ASYM_MF of the 16 row fragments, their SIMD
+    // partners the rest; the partner body has no LDS-DMA code.
+#if WG_ASYM
+    static_assert(LW == 4, "asymmetric split assumes waves 0-3 load");
+    if (__builtin_amdgcn_readfirstlane(wave) < 4) tile_body(WIntC<WG_ASYM_MF>{}, WIntC<1>{}, 0);
+    else tile_body(WIntC<16 - WG_ASYM_MF>{}, WIntC<0>{}, WG_ASYM_MF * 16);
+#else
+    tile_body(WIntC<8>{}, WIntC<1>{}, wm * 128);
+#endif
     __syncthreads();
     {
         const int cc = tid & 31, r0 = tid >> 5;  // 32 chunks per row, 16 rows per pass
