@@ -37,6 +37,18 @@ __device__ __forceinline__ float bf2f(bf16_t b) {
 }
 // round an fp32 value to the nearest bf16 and return it as fp32
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+// the same for two values at once (one v_cvt_pk_bf16_f32), and the packed pair itself
+typedef __bf16 moe_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float moe_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2(float x, float y) {
+    const moe_f32x2_t v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, moe_bf16x2_t));
+}
+__device__ __forceinline__ void rbf2(float &x, float &y) {
+    const unsigned u = pack_bf2(x, y);
+    x = __builtin_bit_cast(float, u << 16);
+    y = __builtin_bit_cast(float, u & 0xffff0000u);
+}
 
 __device__ __forceinline__ void unpack8(const uint4 v, float *f) {
     const unsigned u[4] = {v.x, v.y, v.z, v.w};

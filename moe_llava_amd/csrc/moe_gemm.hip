@@ -351,6 +351,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
         __syncthreads();  // every wave is done reading the ring
         if (EPI == EPI_SWIGLU) {
+            // whole tile gated (plain SwiGLU, or a RePaMLP tile below the mask boundary): no per-element select
+            const bool all_gated = ct * NC + NC <= p.n_gated;  // uniform per block
 #pragma unroll
             for (int nf = 0; nf < NF / 2; ++nf) {
                 const int cl = wn * (WNT / 2) + nf * 16 + fq * 4;  // column inside the tile
@@ -365,18 +367,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 }
 #pragma unroll
                 for (int mf = 0; mf < MFW; ++mf) {
-                    unsigned short h[4];
+                    // the reference's rounding points: bf16 outputs of the two Linears, bf16 F.silu, bf16 product;
+                    // roundings go two at a time through v_cvt_pk_bf16_f32
+                    float a[4], b[4], sg[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float a = rbf(acc[nf][mf][j] + ba[j]);            // bf16 output of the 'a' Linear
-                        const float b = rbf(acc[nf + NF / 2][mf][j] + bb[j]);   // bf16 output of the 'b' Linear
-                        // F.silu on a bf16 tensor; RePaMLP: torch.where(mask, silu, 1) (llava_stablelm_moe.py:636-638)
-                        const float sg = (c0 + j < p.n_gated) ? rbf(fast_silu(a)) : 1.0f;
-                        h[j] = f2bf(sg * b);
+                        a[j] = acc[nf][mf][j];
+                        b[j] = acc[nf + NF / 2][mf][j];
+                    }
+                    if (bias) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            a[j] += ba[j];
+                            b[j] += bb[j];
+                        }
+                    }
+                    rbf2(a[0], a[1]); rbf2(a[2], a[3]); rbf2(b[0], b[1]); rbf2(b[2], b[3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sg[j] = fast_silu(a[j]);
+                    rbf2(sg[0], sg[1]); rbf2(sg[2], sg[3]);
+                    if (!all_gated) {
+                        // RePaMLP: torch.where(mask, silu, 1) (llava_stablelm_moe.py:636-638)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sg[j] = (c0 + j < p.n_gated) ? sg[j] : 1.0f;
                     }
                     uint2 o;
-                    o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-                    o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+                    o.x = pack_bf2(sg[0] * b[0], sg[1] * b[1]);
+                    o.y = pack_bf2(sg[2] * b[2], sg[3] * b[3]);
                     *reinterpret_cast<uint2 *>(lds + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
                 }
             }
@@ -392,15 +409,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 }
 #pragma unroll
                 for (int mf = 0; mf < MFW; ++mf) {
-                    unsigned short h[4];
+                    float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float v = rbf(acc[nf][mf][j] + bv[j]);  // bf16 output of the Linear
-                        h[j] = (EPI == EPI_GELU_NEW) ? f2bf(gelu_new_bf16(v)) : f2bf(v);
+                    for (int j = 0; j < 4; ++j) v[j] = acc[nf][mf][j] + bv[j];  // bf16 output of the Linear (rounded below)
+                    if (EPI == EPI_GELU_NEW) {
+                        rbf2(v[0], v[1]); rbf2(v[2], v[3]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_new_bf16(v[j]);
                     }
                     uint2 o;
-                    o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-                    o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+                    o.x = pack_bf2(v[0], v[1]);
+                    o.y = pack_bf2(v[2], v[3]);
                     *reinterpret_cast<uint2 *>(lds + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
                 }
             }
