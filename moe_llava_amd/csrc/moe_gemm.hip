@@ -43,6 +43,9 @@ constexpr int NTHREADS = 512;
 #ifndef GEMM_ASYM_MF
 #define GEMM_ASYM_MF 5  // row fragments (of 16) of a loader wave; its partner owns 16 - this
 #endif
+#ifndef GEMM_PERSIST
+#define GEMM_PERSIST 1  // 256 x 256 launches of more than 256 tiles run as 256 persistent blocks (one per CU)
+#endif
 #ifndef GEMM_PIPE
 #define GEMM_PIPE 1  // software-pipelined fragment reads (0 = all reads of a k-step, one wait, then its MFMAs)
 #endif
@@ -75,7 +78,10 @@ struct Tile {
     static constexpr int NS = (BM == 256 && BNW == 256) ? 2 : (147456 / SLOT_BYTES >= 8 ? 8 : 147456 / SLOT_BYTES);
     static constexpr int NC = (EPI == EPI_SWIGLU) ? BNW / 2 : BNW;  // output columns per tile
     static constexpr int ROWB = NC * 2 + EPI_PAD;                   // bytes per image row
-    static constexpr int LDS_BYTES = NS * SLOT_BYTES > BM * ROWB ? NS * SLOT_BYTES : BM * ROWB;
+    // persistent SwiGLU launches of the big tile put the output image behind ring slot 0 (see the kernel)
+    static constexpr bool OVERLAP = GEMM_PERSIST && EPI == EPI_SWIGLU && BM == 256 && BNW == 256;
+    static constexpr int IMG_BYTES = (OVERLAP ? SLOT_BYTES : 0) + BM * ROWB;
+    static constexpr int LDS_BYTES = NS * SLOT_BYTES > IMG_BYTES ? NS * SLOT_BYTES : IMG_BYTES;
     static constexpr int MF = BM / 32;   // 16-row fragments per wave (wave tile BM/2 rows)
     static constexpr int NF = BNW / 64;  // 16-W-row fragments per wave (wave tile BNW/4 W rows)
     static constexpr int WNT = BNW / 4;  // W rows per wave
@@ -110,42 +116,49 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     constexpr int NS = T::NS, MF = T::MF, NF = T::NF, WNT = T::WNT, NC = T::NC, ROWB = T::ROWB;
     __shared__ __attribute__((aligned(16))) char lds[T::LDS_BYTES];
 
-    // ---- block -> (row tile, col tile): XCD-contiguous chunks, then super-rows of RS row tiles ----
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-#ifdef GEMM_NO_XCD
-    const int swz = bid; (void)q8; (void)r8; (void)xcd;
-#else
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-#endif
+    // ---- tiles of this block.  One-tile-per-block launches have gridDim.x == n_virtual; persistent launches (256 blocks,
+    //      one per CU) walk the same virtual block ids with stride gridDim.x (a multiple of 8, so a block keeps its XCD).
+    //      virtual block -> (row tile, col tile): XCD-contiguous chunks, then super-rows of RS row tiles ----
+    struct TileC { int ct, row_begin, row_end, expert; };
     const int CT = p.col_tiles;
-    const int per_sr = RS * CT;
-    const int sr = swz / per_sr;
-    const int rem = swz - sr * per_sr;
-    const int rows_in = min(RS, p.max_row_tiles - sr * RS);
-    const int ct = rem / rows_in;
-    const int rt = sr * RS + (rem - ct * rows_in);
-
-    // ---- row tile -> group (expert), row range ----
-    int row_begin = 0, row_end = 0, grp = -1;
-    {
+    const int n_virtual = p.max_row_tiles * CT;
+    auto map_tile = [&](int vb, TileC &c) -> bool {
+        const int q8 = n_virtual >> 3, r8 = n_virtual & 7, xcd = vb & 7;
+#ifdef GEMM_NO_XCD
+        const int swz = vb; (void)q8; (void)r8; (void)xcd;
+#else
+        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+#endif
+        const int per_sr = RS * CT;
+        const int sr = swz / per_sr;
+        const int rem = swz - sr * per_sr;
+        const int rows_in = min(RS, p.max_row_tiles - sr * RS);
+        const int ctile = rem / rows_in;
+        const int rt = sr * RS + (rem - ctile * rows_in);
+        // row tile -> group (expert), row range
         int tile0 = 0;
         for (int g = 0; g < p.G; ++g) {
             const int b = p.group_offsets[g], e = p.group_offsets[g + 1];
             const int nt = (e - b + BM - 1) / BM;
             if (rt < tile0 + nt) {
-                grp = g;
-                row_begin = b + (rt - tile0) * BM;
-                row_end = e;
-                break;
+                c.ct = ctile;
+                c.row_begin = b + (rt - tile0) * BM;
+                c.row_end = e;
+                c.expert = g % p.n_experts;
+                return true;
             }
             tile0 += nt;
         }
-    }
-    if (grp < 0) return;  // surplus block of the worst-case grid (uniform per block)
-    const int expert = grp % p.n_experts;
-    const bf16_t *wbase = p.w + (long long)expert * p.w_expert_stride;
+        return false;  // surplus tile of the worst-case grid
+    };
+    auto next_tile = [&](int vb, TileC &c) {  // first real tile of this block at or after virtual block vb
+        while (vb < n_virtual && !map_tile(vb, c)) vb += (int)gridDim.x;
+        return vb;
+    };
+    TileC cur, nxt;
+    int vb = next_tile((int)blockIdx.x, cur);
+    if (vb >= n_virtual) return;  // uniform per block
+    int ct = cur.ct, row_begin = cur.row_begin, row_end = cur.row_end, expert = cur.expert;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -172,14 +185,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     auto xsw = [](int row) { return (row >> 1) & 7; };
     const bf16_t *a_src[NPX];
     const bf16_t *w_src[NPW];
-    {
+    auto setup_ptrs = [&](const TileC &tc) {
+        const bf16_t *wb = p.w + (long long)tc.expert * p.w_expert_stride;
         const int rr = lane / CH, c = lane % CH;
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
             const int row = (lwave * NPX + j) * PR + rr;  // 0..BM-1
             const int cs = c ^ xsw(row);
-            int prow = row_begin + row;
-            if (prow > row_end - 1) prow = row_end - 1;  // clamp: rows past the group end are never stored
+            int prow = tc.row_begin + row;
+            if (prow > tc.row_end - 1) prow = tc.row_end - 1;  // clamp: rows past the group end are never stored
             const long long srow = p.gather ? (long long)(p.gather[prow] >> p.gather_shift) : (long long)prow;
             a_src[j] = p.a + srow * p.lda + cs * 8;
         }
@@ -191,14 +205,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             if (EPI == EPI_SWIGLU) {
                 // wave wn' owns LDS W rows [wn'*WNT, +WNT): first half 'a' rows, second half 'b' rows of its columns
                 const int wq = row / WNT, within = row % WNT;
-                const int col = ct * NC + wq * (WNT / 2) + (within % (WNT / 2));
+                const int col = tc.ct * NC + wq * (WNT / 2) + (within % (WNT / 2));
                 wrow = min(col, p.N_out - 1) + (within / (WNT / 2)) * p.b_row_offset;
             } else {
-                wrow = min(ct * BNW + row, p.N_out - 1);
+                wrow = min(tc.ct * BNW + row, p.N_out - 1);
             }
-            w_src[j] = wbase + (long long)wrow * p.K + cs * 8;
+            w_src[j] = wb + (long long)wrow * p.K + cs * 8;
         }
-    }
+    };
     bf16_t *const lds_e = reinterpret_cast<bf16_t *>(lds);
     const int nk = p.K / BK;  // >= 1 (K % 64 == 0)
     auto stage = [&](int buf, int kt) {
@@ -223,7 +237,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 
     // K loop and register epilogue for a wave that owns MFW 16-row fragments starting at tile row row_off.  The two
     // waves of a SIMD (wave w and w + 4) may own different shares: see ASYM below.
-    auto tile_body = [&](auto mfw_c, auto loads_c, const int row_off) {
+    // OVERLAP: persistent 256 x 256 SwiGLU launches keep the output image behind ring slot 0, so that the next tile's
+    // first slice can land in slot 0 during the epilogue.
+    constexpr bool OVERLAP = T::OVERLAP;
+    char *const img = lds + (OVERLAP ? T::SLOT_BYTES : 0);
+
+    auto tile_body = [&](auto mfw_c, auto loads_c, const int row_off, const bool staged, const bool have_next) {
         constexpr int MFW = decltype(mfw_c)::value;
         constexpr bool LOADS = decltype(loads_c)::value != 0;  // false: this wave never issues LDS-DMA (pointers dead)
         const int x_off = (row_off + fr) * BK;
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         // instructions per loader wave each.
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s)
-            if (LOADS && s < nk) stage(s, s);
+            if (LOADS && !staged && s < nk) stage(s, s);
 #ifdef GEMM_STAMPS
         st_t0 = stamp(); st_begin = st_t0;
 #endif
@@ -350,6 +369,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         // ---- epilogue: activation in registers -> bf16 tile image in LDS -> 16-byte, full-line global stores ----
         const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
         __syncthreads();  // every wave is done reading the ring
+        if (OVERLAP && LOADS && have_next) {
+            // persistent launch: the loader waves start the next tile (pointers, first slice into ring slot 0) while the
+            // epilogue runs; the output image sits behind slot 0 for that
+            setup_ptrs(nxt);
+            stage(0, 0);
+        }
         if (EPI == EPI_SWIGLU) {
             // whole tile gated (plain SwiGLU, or a RePaMLP tile below the mask boundary): no per-element select
             const bool all_gated = ct * NC + NC <= p.n_gated;  // uniform per block
@@ -394,7 +419,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                     uint2 o;
                     o.x = pack_bf2(sg[0] * b[0], sg[1] * b[1]);
                     o.y = pack_bf2(sg[2] * b[2], sg[3] * b[3]);
-                    *reinterpret_cast<uint2 *>(lds + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
+                    *reinterpret_cast<uint2 *>(img + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
                 }
             }
         } else {
@@ -420,7 +445,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                     uint2 o;
                     o.x = pack_bf2(v[0], v[1]);
                     o.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<uint2 *>(lds + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
+                    *reinterpret_cast<uint2 *>(img + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
                 }
             }
         }
@@ -433,56 +458,75 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     // MFMA operands per output element: bit-identical.  Measured (same-process A/B, config 2): fc2 862 -> 814 us
     // (+5.9 %), fc1 1622 -> 1593 us (+1.8 %); splits 4/12, 6/10, 7/9 are within 1.5 % of 5/11.
     constexpr bool ASYM = GEMM_ASYM && BM == 256 && BNW == 256 && LW == 4;
-    if (ASYM) {
-        if (__builtin_amdgcn_readfirstlane(wave) < 4) tile_body(IntC<GEMM_ASYM_MF>{}, IntC<1>{}, 0);
-        else tile_body(IntC<16 - GEMM_ASYM_MF>{}, IntC<0>{}, GEMM_ASYM_MF * 16);
-    } else {
-        tile_body(IntC<MF>{}, IntC<1>{}, wm * (BM / 2));
-    }
-    __syncthreads();
-    {
-        constexpr int CPR = NC / 8;                    // 16-byte chunks per row
-        constexpr int ROWS_PER_IT = NTHREADS / CPR;    // rows covered by one pass of the block
-        const int cc = tid % CPR, r0 = tid / CPR;
-        const int col = ct * NC + cc * 8;
-        const int ncols_ok = p.N_out - col;            // > 0 columns valid from here (N_out % 4 == 0)
+    // The tile loop (one pass for one-tile-per-block launches), instantiated per wave role so that the staging pointers
+    // are dead in the partner waves' whole loop.
+    auto run_tiles = [&](auto mfw_c, auto loads_c, const int row_off) {
+        constexpr bool LOADS_W = decltype(loads_c)::value != 0;
+        bool staged = false;
+        while (true) {
+            if (LOADS_W && loader && !staged) setup_ptrs(cur);
+            const int vbn = next_tile(vb + (int)gridDim.x, nxt);
+            const bool have_next = vbn < n_virtual;
+            tile_body(mfw_c, loads_c, row_off, staged, have_next);
+            __syncthreads();
+            {
+                constexpr int CPR = NC / 8;                    // 16-byte chunks per row
+                constexpr int ROWS_PER_IT = NTHREADS / CPR;    // rows covered by one pass of the block
+                const int cc = tid % CPR, r0 = tid / CPR;
+                const int col = ct * NC + cc * 8;
+                const int ncols_ok = p.N_out - col;            // > 0 columns valid from here (N_out % 4 == 0)
 #pragma unroll 4
-        for (int r = r0; r < BM; r += ROWS_PER_IT) {
-            const int prow = row_begin + r;
-            if (prow < row_end && ncols_ok > 0) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(lds + r * ROWB + cc * 16);
-                bf16_t *dst = p.out + (long long)prow * p.ldo + col;
-                if (EPI == EPI_DSWIGLU || EPI == EPI_DGELU) {
-                    // v = 8 elements of dH (bf16, as the standalone path stores them); N_out % 8 == 0 here
-                    const bf16_t *abrow = p.aux + (long long)prow * p.ld_aux + col;
-                    float g[8], a[8];
-                    unpack8(v, g);
-                    unpack8(*reinterpret_cast<const uint4 *>(abrow), a);
-                    if (EPI == EPI_DSWIGLU) {
-                        float b[8], da[8], db[8];
-                        unpack8(*reinterpret_cast<const uint4 *>(abrow + p.b_row_offset), b);
-                        swiglu_bwd8(a, b, g, col, p.n_gated, da, db);
-                        *reinterpret_cast<uint4 *>(dst) = pack8(da);
-                        *reinterpret_cast<uint4 *>(dst + p.b_row_offset) = pack8(db);
-                    } else {
-                        float dx[8];
-                        gelu_new_bwd8(a, g, dx);
-                        *reinterpret_cast<uint4 *>(dst) = pack8(dx);
-                    }
-                } else if (ncols_ok >= 8) {
+                for (int r = r0; r < BM; r += ROWS_PER_IT) {
+                    const int prow = row_begin + r;
+                    if (prow < row_end && ncols_ok > 0) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(img + r * ROWB + cc * 16);
+                        bf16_t *dst = p.out + (long long)prow * p.ldo + col;
+                        if (EPI == EPI_DSWIGLU || EPI == EPI_DGELU) {
+                            // v = 8 elements of dH (bf16, as the standalone path stores them); N_out % 8 == 0 here
+                            const bf16_t *abrow = p.aux + (long long)prow * p.ld_aux + col;
+                            float g[8], a[8];
+                            unpack8(v, g);
+                            unpack8(*reinterpret_cast<const uint4 *>(abrow), a);
+                            if (EPI == EPI_DSWIGLU) {
+                                float b[8], da[8], db[8];
+                                unpack8(*reinterpret_cast<const uint4 *>(abrow + p.b_row_offset), b);
+                                swiglu_bwd8(a, b, g, col, p.n_gated, da, db);
+                                *reinterpret_cast<uint4 *>(dst) = pack8(da);
+                                *reinterpret_cast<uint4 *>(dst + p.b_row_offset) = pack8(db);
+                            } else {
+                                float dx[8];
+                                gelu_new_bwd8(a, g, dx);
+                                *reinterpret_cast<uint4 *>(dst) = pack8(dx);
+                            }
+                        } else if (ncols_ok >= 8) {
 #if GEMM_NT_STORE
-                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                    u32x4_t vv = {v.x, v.y, v.z, v.w};
-                    __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_t *>(dst));
+                            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                            u32x4_t vv = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_t *>(dst));
 #else
-                    *reinterpret_cast<uint4 *>(dst) = v;
+                            *reinterpret_cast<uint4 *>(dst) = v;
 #endif
-                } else {
-                    *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
+                        } else {
+                            *reinterpret_cast<uint2 *>(dst) = make_uint2(v.x, v.y);
+                        }
+                    }
                 }
             }
+            if (!have_next) break;
+            if (!OVERLAP) __syncthreads();  // the image has been read before the next tile's first slice lands on it
+            staged = OVERLAP;
+            vb = vbn;
+            cur = nxt;
+            ct = cur.ct; row_begin = cur.row_begin; row_end = cur.row_end; expert = cur.expert;
         }
+    };
+    if (ASYM) {
+        if (__builtin_amdgcn_readfirstlane(wave) < 4) run_tiles(IntC<GEMM_ASYM_MF>{}, IntC<1>{}, 0);
+        else run_tiles(IntC<16 - GEMM_ASYM_MF>{}, IntC<0>{}, GEMM_ASYM_MF * 16);
+    } else {
+        run_tiles(IntC<MF>{}, IntC<1>{}, wm * (BM / 2));
     }
+
 #ifdef GEMM_STAMPS
     {
         const unsigned long long st_end = stamp();
@@ -531,9 +575,14 @@ static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     constexpr int NC = Tile<EPI, BM, BNW>::NC;
     p.max_row_tiles = max_rows_or_neg / BM + p.G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
     p.col_tiles = (p.N_out + NC - 1) / NC;
-    const long long grid = (long long)p.max_row_tiles * p.col_tiles;
+    long long grid = (long long)p.max_row_tiles * p.col_tiles;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffffLL) return fail(MOE_ERR_SHAPE, "grouped_gemm: grid too large");
+    // big-tile launches: one persistent block per CU walks the tile list (no block hand-over between tiles, and for
+    // SwiGLU the next tile's first fills overlap the epilogue); MOE_NO_PERSIST=1 keeps one block per tile
+    // (measured: fc1 of config 2, 7832 tiles, -1.3 %; launches of a few rounds gain nothing and, being 256 resident
+    // blocks, could no longer interleave with a second stream's launch, so they keep one block per tile)
+    if (GEMM_PERSIST && BM == 256 && BNW == 256 && grid >= 4096 && !getenv("MOE_NO_PERSIST")) grid = 256;
     hipLaunchKernelGGL((grouped_gemm_kernel<EPI, BM, BNW>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, p);
     return check_launch("grouped_gemm_kernel");
 }
