@@ -89,6 +89,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
+    (void)wm;  // used only by the symmetric split (WG_ASYM = 0)
     const int fr = lane & 15, fq = lane >> 4;
 
     // ---- staging: piece q (0..31) of a tile = k rows 2q, 2q+1; lane -> k row 2q + (lane >> 5), LDS chunk lane & 31,
