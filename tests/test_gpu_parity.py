@@ -517,30 +517,35 @@ def test_decode_gate_and_routing_in_one_launch_is_bit_identical(S, E, wg_bf16):
     assert torch.equal(r.perm[:n], r2.perm[:n]) and torch.equal(out, out2)
 
 
-def test_persistent_launch_equals_one_block_per_tile():
+@pytest.mark.parametrize("epilogue", [1, 0, 2])
+def test_persistent_launch_equals_one_block_per_tile(epilogue):
     """Launches of >= 4096 big tiles run as 256 persistent blocks that walk the tile list (for SwiGLU with the next
-    tile's first fills issued during the epilogue); MOE_NO_PERSIST=1 keeps one block per tile.  Same bits."""
+    tile's first fills issued during the epilogue); MOE_NO_PERSIST=1 keeps one block per tile.  Same bits, for the
+    SwiGLU (1), plain (0) and gelu_new + bias (2) epilogues."""
     import os
     from moe_llava_amd import _lib
     lib = _lib.load()
-    M, I, E, R = 1024, 5632, 4, 25000                      # fc1: 98+ row tiles x 44 column tiles > 4096 tiles
+    M, I, E, R = 1024, 5632, 4, 25000                      # 98+ row tiles x 44 column tiles > 4096 tiles
     g = torch.Generator().manual_seed(3)
     x = torch.randn(R // 2, M, generator=g).to(torch.bfloat16).to(DEV)
     w1 = (torch.randn(E, 2 * I, M, generator=g) * 0.03).to(torch.bfloat16).to(DEV)
+    b1 = (torch.randn(E, 2 * I, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
     cnt = torch.tensor([9000, 1, 7000, R - 16001])
     offs = torch.zeros(E + 1, dtype=torch.int32)
     offs[1:] = torch.cumsum(cnt, 0).int()
     offs = offs.to(DEV)
     perm = torch.randperm(R, generator=g).int().to(DEV)    # token * 2 + choice, any order
     st = torch.cuda.current_stream().cuda_stream
+    N = I if epilogue == 1 else 2 * I                      # output columns (SwiGLU halves the 2I weight rows)
     outs = []
     for env in (None, "1"):
         if env:
             os.environ["MOE_NO_PERSIST"] = env
         try:
-            h = torch.zeros(R, I, dtype=torch.bfloat16, device=DEV)
-            rc = lib.moe_grouped_gemm_fwd(1, x.data_ptr(), M, perm.data_ptr(), 1, w1.data_ptr(), None, offs.data_ptr(), E, E,
-                                          R, M, I, -1, h.data_ptr(), I, st)
+            h = torch.zeros(R, N, dtype=torch.bfloat16, device=DEV)
+            rc = lib.moe_grouped_gemm_fwd(epilogue, x.data_ptr(), M, perm.data_ptr(), 1, w1.data_ptr(),
+                                          b1.data_ptr() if epilogue == 2 else None, offs.data_ptr(), E, E,
+                                          R, M, N, -1, h.data_ptr(), N, st)
             assert rc == 0, lib.moe_last_error()
             torch.cuda.synchronize()
             outs.append(h)
@@ -554,6 +559,12 @@ def test_persistent_launch_equals_one_block_per_tile():
         if rows.numel() == 0:
             continue
         xr = x[(perm[rows] >> 1).long()].float()
-        ab = (xr @ w1[e].float().t()).to(torch.bfloat16).float()
-        want = (torch.nn.functional.silu(ab[:, :I]).to(torch.bfloat16).float() * ab[:, I:]).to(torch.bfloat16)
-        assert torch.allclose(outs[0][rows].float(), want.float(), rtol=2e-2, atol=2e-2)
+        ab = xr @ w1[e].float().t()
+        if epilogue == 1:
+            ab = ab.to(torch.bfloat16).float()
+            want = (torch.nn.functional.silu(ab[:, :I]).to(torch.bfloat16).float() * ab[:, I:]).to(torch.bfloat16)
+        elif epilogue == 0:
+            want = ab.to(torch.bfloat16)
+        else:
+            want = torch.nn.functional.gelu((ab + b1[e].float()).to(torch.bfloat16).float(), approximate="tanh").to(torch.bfloat16)
+        assert torch.allclose(outs[0][rows].float(), want.float(), rtol=3e-2, atol=3e-2)
