@@ -149,6 +149,7 @@ struct GemmParams {
     int n_gated;       // gated: output columns >= n_gated bypass SiLU (RePaMLP mask); = N_out for plain SwiGLU
     int max_row_tiles;
     int col_tiles;
+    int rs;            // row tiles per super-row of the block -> tile map (moe_gemm.hip)
     const bf16_t *aux;  // EPI_DSWIGLU / EPI_DGELU: pre-activations AB [rows, ld_aux]
     long long ld_aux;
 };

@@ -28,7 +28,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 constexpr int BK = 64;  // K slice per ring slot
 constexpr int NTHREADS = 512;
 #ifndef GEMM_RS
-#define GEMM_RS 4
+#define GEMM_RS 0  // > 0: force the super-row height (experiments); 0: host rule (launch_tile)
 #endif
 #ifndef GEMM_AUX
 #define GEMM_AUX 0
@@ -49,7 +49,7 @@ constexpr int NTHREADS = 512;
 #ifndef GEMM_PIPE
 #define GEMM_PIPE 1  // software-pipelined fragment reads (0 = all reads of a k-step, one wait, then its MFMAs)
 #endif
-constexpr int RS = GEMM_RS;  // row tiles per super-row (L2 reuse of the W panel inside an XCD)
+// row tiles per super-row (L2 reuse of the W panel inside an XCD): GemmParams::rs
 
 __device__ __forceinline__ void glds16(const bf16_t *gsrc, bf16_t *lds_wave_base) {
     __builtin_amdgcn_global_load_lds(
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #else
         const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
 #endif
+        const int RS = p.rs;
         const int per_sr = RS * CT;
         const int sr = swz / per_sr;
         const int rem = swz - sr * per_sr;
@@ -575,6 +576,9 @@ static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     constexpr int NC = Tile<EPI, BM, BNW>::NC;
     p.max_row_tiles = max_rows_or_neg / BM + p.G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
     p.col_tiles = (p.N_out + NC - 1) / NC;
+    // super-row height: 4 row tiles (an XCD's 32 CUs then work on 4 x 8 tiles); launches with few column tiles (fc2 of
+    // config 2: 8) measured 2 % faster with 3 (same-process A/B: 811 -> 793 us; fc1 with 44 column tiles 0.7 % slower)
+    p.rs = GEMM_RS > 0 ? GEMM_RS : (p.col_tiles <= 8 ? 3 : 4);
     long long grid = (long long)p.max_row_tiles * p.col_tiles;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffffLL) return fail(MOE_ERR_SHAPE, "grouped_gemm: grid too large");
