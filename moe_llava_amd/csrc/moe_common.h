@@ -168,7 +168,7 @@ int launch_skinny_gemm(const GemmParams &p, int epilogue, int max_rows, hipStrea
 int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst, hipStream_t st);
 // dW_e[R, N] = A[rows of expert e]^T @ B[rows of expert e] (moe_wgrad.hip)
 int launch_wgrad_tn(const bf16_t *a, long long lda, const bf16_t *b, long long ldb, const int *group_offsets, int G,
-                    int n_experts, int R, int N, bf16_t *out, hipStream_t st);
+                    int n_experts, int max_rows, int R, int N, bf16_t *out, hipStream_t st);
 int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, int n_gated, bf16_t *h,
                    hipStream_t st);
 // out[e, n] = sum over the rows of expert e's groups of d[r, n]  (fp32, zeroed here)

@@ -779,6 +779,16 @@ extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int
     for (const void *q : {a, w1, w2, ab, h, dy, (const void *)da_rows, (const void *)dw1, (const void *)dw2,
                           (const void *)workspace, (const void *)db1, (const void *)db2})
         if (q && !aligned16(q)) return fail(MOE_ERR_ALIGN, "%s: pointers must be 16-byte aligned", fn);
+    {
+        // the weight-gradient kernel addresses a group's rows by 32-bit byte offsets (moe_wgrad.hip): refuse here, before
+        // anything is launched, what launch_wgrad_tn would refuse half-way through
+        const long long n1 = act == MOE_ACT_SWIGLU ? 2ll * I : (long long)I;
+        long long ldmax = n1 > M ? n1 : M;
+        if (lda > ldmax) ldmax = lda;
+        if (((long long)max_rows + 64) * ldmax * 2 >= (1ll << 32))
+            return fail(MOE_ERR_SHAPE, "%s: %d rows x row stride %lld exceed the weight-gradient kernel's 4 GiB per group",
+                        fn, max_rows, ldmax);
+    }
     const BwdWs ws = carve_bwd(workspace, act, G, n_experts_local, max_rows, M, I);
     if (ws_bytes < ws.total) return fail(MOE_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, ws_bytes, ws.total);
     hipStream_t st = (hipStream_t)stream;
@@ -793,7 +803,7 @@ extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int
     if ((rc = grouped_gemm_launch(fn, act == MOE_ACT_SWIGLU ? EPI_DSWIGLU : EPI_DGELU, dy, M, nullptr, 0, ws.wt, nullptr,
                                   group_offsets, G, El, max_rows, M, I, n_gated, ws.dab, N1, ab, N1, stream)))
         return rc;
-    if ((rc = launch_wgrad_tn(dyp, M, (const bf16_t *)h, I, group_offsets, G, El, M, I, (bf16_t *)dw2, st))) return rc;
+    if ((rc = launch_wgrad_tn(dyp, M, (const bf16_t *)h, I, group_offsets, G, El, max_rows, M, I, (bf16_t *)dw2, st))) return rc;
     if (db2 && (rc = launch_bias_grad(dyp, group_offsets, G, El, max_rows, M, db2, st))) return rc;
     // ---- fc1: dA = dAB @ W1, dW1 = dAB^T @ A, db1 = colsum(dAB) ----
     if ((rc = launch_transpose_batched((const bf16_t *)w1, El, N1, M, ws.wt, st))) return rc;  // W1^T [El, M, N1]
@@ -809,7 +819,7 @@ extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int
         xrows = ws.xr;
         ldx = M;
     }
-    if ((rc = launch_wgrad_tn(ws.dab, N1, xrows, ldx, group_offsets, G, El, N1, M, (bf16_t *)dw1, st))) return rc;
+    if ((rc = launch_wgrad_tn(ws.dab, N1, xrows, ldx, group_offsets, G, El, max_rows, N1, M, (bf16_t *)dw1, st))) return rc;
     if (db1 && (rc = launch_bias_grad(ws.dab, group_offsets, G, El, max_rows, N1, db1, st))) return rc;
     return 0;
 }

@@ -297,7 +297,14 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
 
 // out[e] ([R, N] bf16) = A[rows of e]^T @ B[rows of e];  R, N multiples of 8, >= 8
 int launch_wgrad_tn(const bf16_t *a, long long lda, const bf16_t *b, long long ldb, const int *group_offsets, int G,
-                    int n_experts, int R, int N, bf16_t *out, hipStream_t st) {
+                    int n_experts, int max_rows, int R, int N, bf16_t *out, hipStream_t st) {
+    // the kernel addresses a group's rows by 32-bit byte offsets from the group base: a group can hold at most max_rows
+    // rows, so (max_rows + 64) * ld * 2 must stay below 4 GiB (e.g. 190 k rows at ld = 2 * 5632); refuse beyond that
+    // instead of computing the gradient from wrong rows
+    const long long ldmax = lda > ldb ? lda : ldb;
+    if (((long long)max_rows + WBK) * ldmax * 2 >= (1ll << 32))
+        return fail(MOE_ERR_SHAPE, "wgrad: %d rows x row stride %lld exceed the kernel's 32-bit row offsets (4 GiB per group)",
+                    max_rows, ldmax);
     WgradParams p;
     p.a = a; p.lda = lda; p.b = b; p.ldb = ldb;
     p.group_offsets = group_offsets; p.G = G; p.n_experts = n_experts;
@@ -305,6 +312,8 @@ int launch_wgrad_tn(const bf16_t *a, long long lda, const bf16_t *b, long long l
     p.r_tiles = (R + WT - 1) / WT;
     p.n_tiles = (N + WT - 1) / WT;
     const long long grid = (long long)n_experts * p.r_tiles * p.n_tiles;
+    if (grid <= 0) return 0;
+    if (grid > 0x7fffffffLL) return fail(MOE_ERR_SHAPE, "wgrad: grid too large");
     hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)grid), dim3(WTHREADS), 0, st, p);
     return check_launch("wgrad_tn_kernel");
 }

@@ -78,6 +78,15 @@ def _adapt_builtin(e: nn.Module) -> Optional[ExpertSpec]:
     return None
 
 
+def _is_foreign_view(p: Tensor, mine) -> bool:
+    """True when ``p`` is a view into a storage larger than itself that is not one of the packed buffers in ``mine``
+    (storage base addresses): its memory has another owner."""
+    st = p.untyped_storage()
+    if st.data_ptr() in mine:
+        return False
+    return p.storage_offset() != 0 or st.nbytes() > p.numel() * p.element_size()
+
+
 def describe_expert(e: nn.Module) -> ExpertSpec:
     for fn in _ADAPTERS + [_adapt_builtin]:
         spec = fn(e)
@@ -100,6 +109,8 @@ class Experts(nn.Module):
                 p.group_name = expert_group_name
         self._packed: Optional[Dict[str, Optional[Tensor]]] = None
         self._ptrs: Optional[List[int]] = None
+        #: the parameters live in somebody else's flat buffer: never re-pointed, copied into the packed layout per forward
+        self._external: bool = False
         #: SwiGLU channels >= n_gated skip the SiLU (RePaMLP experts); -1 = ordinary experts.  Refreshed per forward.
         self.n_gated: int = -1
 
@@ -141,6 +152,8 @@ class Experts(nn.Module):
         ptrs = [(p.data_ptr(), tuple(p.shape)) for p in params]   # reparam() keeps the address and shrinks the shape
         if self._packed is not None and ptrs == self._ptrs and self._packed["w1"].device == device:
             pk = self._packed
+            if self._external:
+                self._copy_in(specs, pk)
             return specs[0].act, pk["w1"], pk["b1"], pk["w2"], pk["b2"]
         for p in params:
             if p.dtype != torch.bfloat16:
@@ -167,32 +180,58 @@ class Experts(nn.Module):
         has_b1 = specs[0].fc1[0].bias is not None
         has_b2 = specs[0].fc2.bias is not None
         kw = dict(dtype=torch.bfloat16, device=device)
+        for s in specs:
+            if any((lin.bias is not None) != has_b1 for lin in s.fc1):
+                raise ValueError("bias must be present on all fc1 projections or none")
+            if (s.fc2.bias is not None) != has_b2:
+                raise ValueError("bias must be present on all fc2 projections or none")
+        # Who owns the parameters' memory?  A parameter that is a view into a larger storage which is not one of OUR
+        # packed buffers belongs to somebody else -- an engine that flattened the parameters into one buffer and
+        # updates that buffer in place (DeepSpeed ZeRO-1/2 bf16, which is how the reference trains: scripts/zero2.json).
+        # Taking such parameters away from their owner would silently stop the weight updates from reaching the
+        # kernels, so they are never re-pointed: the packed buffers are then a COPY refreshed on every forward.
+        mine = set()
+        if self._packed is not None:
+            mine = {t.untyped_storage().data_ptr() for t in self._packed.values() if t is not None}
+        external = any(_is_foreign_view(p, mine) for p in params)
+        if external and not self._external:
+            import warnings
+            warnings.warn("moe_llava_amd.Experts: expert parameters are views into a buffer owned by someone else (a "
+                          "flattening optimizer / engine); they are left where they are and copied into the packed "
+                          "kernel layout on every forward (one pass over the expert weights per call)", stacklevel=3)
         w1 = torch.zeros((E, nproj * Ip, M), **kw)
         w2 = torch.zeros((E, M, Ip), **kw)
         b1 = torch.zeros((E, nproj * Ip), **kw) if has_b1 else None
         b2 = torch.zeros((E, M), **kw) if has_b2 else None
-        with torch.no_grad():
-            for i, s in enumerate(specs):
-                for j, lin in enumerate(s.fc1):
-                    if (lin.bias is not None) != has_b1:
-                        raise ValueError("bias must be present on all fc1 projections or none")
-                    v = w1[i, j * Ip:j * Ip + I]
-                    v.copy_(lin.weight.data)
-                    lin.weight.data = v
-                    if has_b1:
-                        bv = b1[i, j * Ip:j * Ip + I]
-                        bv.copy_(lin.bias.data)
-                        lin.bias.data = bv
-                if (s.fc2.bias is not None) != has_b2:
-                    raise ValueError("bias must be present on all fc2 projections or none")
-                w2[i, :, :I].copy_(s.fc2.weight.data)
-                s.fc2.weight.data = w2[i, :, :I]
-                if has_b2:
-                    b2[i].copy_(s.fc2.bias.data)
-                    s.fc2.bias.data = b2[i]
-        self._packed = {"w1": w1, "b1": b1, "w2": w2, "b2": b2}
+        pk = {"w1": w1, "b1": b1, "w2": w2, "b2": b2}
+        self._copy_in(specs, pk)
+        if not external:
+            for lin, wv, bv in self._views(specs, pk):
+                lin.weight.data = wv
+                if bv is not None:
+                    lin.bias.data = bv
+        self._packed = pk
+        self._external = external
         self._ptrs = [(p.data_ptr(), tuple(p.shape)) for p in self._params(specs)]
         return specs[0].act, w1, b1, w2, b2
+
+    def _views(self, specs, pk):
+        """(nn.Linear, weight view, bias view | None) of every projection in the packed buffers ``pk``."""
+        I = specs[0].fc1[0].weight.shape[0]
+        Ip = pk["w2"].shape[2]
+        for i, s in enumerate(specs):
+            for j, lin in enumerate(s.fc1):
+                yield lin, pk["w1"][i, j * Ip:j * Ip + I], (pk["b1"][i, j * Ip:j * Ip + I] if pk["b1"] is not None else None)
+            yield s.fc2, pk["w2"][i, :, :I], (pk["b2"][i] if pk["b2"] is not None else None)
+
+    def _copy_in(self, specs, pk) -> None:
+        """parameters -> packed buffers (a no-op copy onto itself never happens: callers use it only for parameters
+        that live elsewhere)."""
+        with torch.no_grad():
+            for lin, wv, bv in self._views(specs, pk):
+                wv.copy_(lin.weight.data)
+                if bv is not None:
+                    bv.copy_(lin.bias.data)
 
     # ---- autograd plumbing -------------------------------------------------------------------
     def param_list(self) -> List[nn.Parameter]:

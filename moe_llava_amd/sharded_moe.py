@@ -78,11 +78,14 @@ class TopKGate(nn.Module):
     def forward(self, x: Tensor, used_token: Optional[Tensor] = None) -> ops.Routing:
         """Returns the index-form routing (upstream returns dense combine/dispatch masks; nothing in the
         reference tree calls the gate directly)."""
-        if self.noisy_gate_policy == "Jitter":
-            raise NotImplementedError("noisy_gate_policy='Jitter' (multiplicative jitter of the gate input) is not "
-                                      "implemented; the reference never sets it")
-        if self.k == 2 and used_token is not None:
-            raise NotImplementedError("used_token is ignored by upstream top2gating; pass it only with k=1")
+        # upstream applies a noisy-gate policy only while training: 'Jitter' multiplies the gate input when
+        # `self.training`, and top1gating is handed `noisy_gate_policy if self.training else None`
+        if self.noisy_gate_policy == "Jitter" and self.training:
+            raise NotImplementedError("noisy_gate_policy='Jitter' (multiplicative jitter of the gate input while "
+                                      "training) is not implemented; the reference never sets it")
+        if self.k == 2:
+            used_token = None   # upstream top2gating takes no used_token: TopKGate.forward drops it for k = 2
+                                # (RePaMoE.forward passes *args through blindly, llava_stablelm_moe.py:709)
         lg = self.logits(x)
         self.__dict__["last_logits"] = lg   # kept for the backward pass (plain attribute, fast path)
         S, E = lg.shape
@@ -115,7 +118,7 @@ class TopKGate(nn.Module):
             raise AssertionError("No. of tokens (batch-size) should be greater than min_capacity. Either set "
                                  "min_capacity to 0 or increase your batch size.")
         noise, nseed = None, 0
-        if self.noisy_gate_policy == "RSample":
+        if self.noisy_gate_policy == "RSample" and self.training:     # eval routing is noise-free upstream
             noise = self.noise_override
             nseed = 0 if noise is not None else _fresh_seed()
         uni, rseed = None, 0
@@ -232,9 +235,11 @@ class MOELayer(nn.Module):
         S = x.shape[0]
         t = self.timer
         gate = self.gate
+        if gate.k == 2:
+            used_token = None              # ignored by upstream top2gating
         local = self.ep_size == 1 and not (self.force_exchange and self.ep_group is not None)
         if (local and not save and t is None and used_token is None and gate.k == 2 and not gate.wg._forward_hooks
-                and gate.noisy_gate_policy is None):
+                and not (gate.noisy_gate_policy == "Jitter" and gate.training)):
             # inference on one GPU: the whole block in ONE library call (a decode step is host-bound otherwise)
             experts = self.experts
             act, w1, b1, w2, b2 = experts.packed(x.device)

@@ -197,7 +197,8 @@ class TopKGateRef(nn.Module):
         if self.k == 1:
             return top1gating_dense(logits, cf, self.min_capacity, used_token,
                                     self.drop_tokens, self.use_rts, self.rts_uniform,
-                                    self.noise if self.noisy_gate_policy == "RSample" else None)
+                                    # upstream hands top1gating `noisy_gate_policy if self.training else None`
+                                    self.noise if (self.noisy_gate_policy == "RSample" and self.training) else None)
         noise = None
         if self.top2_2nd_expert_sampling:
             if self.noise is None:

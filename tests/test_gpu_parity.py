@@ -205,6 +205,23 @@ def test_moe_layer_vs_literal_oracle(kind, M, I, E, shape, cf, noisy):
         assert float(out.cpu().reshape(-1, M)[dead].float().abs().max()) == 0.0
 
 
+def test_top2_ignores_used_token_and_eval_ignores_jitter():
+    """Upstream top2gating takes no used_token (TopKGate.forward drops it for k = 2; RePaMoE.forward passes *args
+    through, llava_stablelm_moe.py:709), and a noisy-gate policy only acts while training."""
+    ref, mine, x = _build_pair("stablelm", 64, 128, 4, (2, 40), 1.0, seed=5, training=False)
+    used = torch.zeros(80, dtype=torch.long, device=DEV)
+    with torch.no_grad():
+        a, la, ca = mine(x.to(DEV))
+        b, lb, cb = mine(x.to(DEV), used)
+        mine.deepspeed_moe.gate.noisy_gate_policy = "Jitter"
+        c, lc, cc = mine(x.to(DEV))                           # eval: the policy is ignored
+        mine.train()
+        with pytest.raises(NotImplementedError):
+            mine(x.to(DEV))
+    assert torch.equal(a, b) and torch.equal(ca, cb) and float(la) == float(lb)
+    assert torch.equal(a, c) and torch.equal(ca, cc)
+
+
 def test_eval_mode_uses_eval_capacity_and_s1_decode():
     ref, mine, x = _build_pair("stablelm", 64, 128, 4, (1, 1), 1.0, seed=3, training=False)
     with torch.no_grad():

@@ -149,3 +149,9 @@ def test_top1_block_forward_backward_vs_literal_oracle(kind, M, I, E, shape, cf,
     assert torch.equal(c2.cpu(), rc2)
     err, scale = _report(tag + " eval out", o2.cpu(), r2)
     assert err <= 1e-2 * scale
+    if policy == "RSample":
+        # eval routing is noise-free: upstream hands top1gating `noisy_gate_policy if self.training else None`
+        lg = mine.deepspeed_moe.gate.last_logits
+        keep = used.to(DEV) != 0
+        first = mine.deepspeed_moe.last_routing.expert_idx[:, 0].long()
+        assert torch.equal(first[keep], torch.softmax(lg, 1).argmax(1)[keep])

@@ -49,6 +49,10 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.moe_expert_ffn_fwd(7, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 64, -1, 16, 16, None) == -1
     assert lib.moe_expert_ffn_fwd(0, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 100, -1, 16, 16, None) == -2
     assert lib.moe_combine_fwd(16, 16, 16, 16, 16, 4, 64, 3, 16, None) == -2
+    # weight-gradient kernel: 32-bit byte offsets inside a group -> more than 4 GiB of rows is refused, not mis-addressed
+    assert lib.moe_expert_ffn_bwd(0, 16, 2048, None, 0, 16, 16, 16, 16, 16, 16, 4, 4, 200000, 2048, 5632, -1, 16, 16, None,
+                                  16, None, 16, 1 << 40, None) == -2
+    assert b"4 GiB" in lib.moe_last_error()
 
 
 def test_capacity_matches_oracle_formula():
@@ -192,3 +196,49 @@ def test_repa_expert_adapter_padding_and_reparam_on_cpu():
     bad.mask[100] = True
     with pytest.raises(NotImplementedError):
         Experts(bad, 1, "g").packed(torch.device("cpu"))
+
+
+def test_packed_leaves_externally_owned_parameters_alone():
+    """An engine that flattens parameters into one buffer and updates that buffer in place (DeepSpeed ZeRO-1/2 bf16,
+    scripts/zero2.json) owns the memory: packed() must neither re-point the parameters away from it nor miss its
+    updates -- before and after the first pack."""
+    import warnings
+    from moe_llava_amd.experts import Experts
+
+    def flatten(ex):
+        ps = list(ex.parameters())
+        flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.bfloat16)
+        off = 0
+        for p in ps:
+            flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        return flat, ps
+
+    for flatten_first in (True, False):
+        ex = Experts(StableLMMLP(64, 128).to(torch.bfloat16), 3, "ep_size_1")
+        for p in ex.parameters():
+            p.data.normal_(0, 0.1)
+        if not flatten_first:
+            ex.packed(torch.device("cpu"))                         # parameters become views of the packed buffers
+        flat, ps = flatten(ex)
+        ptrs = [p.data_ptr() for p in ps]
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            act, w1, b1, w2, b2 = ex.packed(torch.device("cpu"))
+        assert any("owned by someone else" in str(x.message) for x in w)
+        assert [p.data_ptr() for p in ps] == ptrs                  # still views of the engine's flat buffer
+        e1 = ex.deepspeed_experts[1]
+        assert torch.equal(w1[1, :128], e1.gate_proj.weight.data) and torch.equal(w2[1], e1.down_proj.weight.data)
+        before = w1.float().mean().item()
+        flat.add_(1.0)                                             # the engine's in-place optimizer step
+        act, w1b, _, w2b, _ = ex.packed(torch.device("cpu"))
+        assert w1b is w1 and abs(w1b.float().mean().item() - (before + 1.0)) < 2e-2
+        assert torch.equal(w2b[2], ex.deepspeed_experts[2].down_proj.weight.data)
+        assert [p.data_ptr() for p in ps] == ptrs
+        # .to() / load_state_dict style replacement (parameters own their storage again): re-pointed as before
+        for p in ps:
+            p.data = p.data.clone()
+        act, w1c, _, _, _ = ex.packed(torch.device("cpu"))
+        assert w1c is not w1 and ex.deepspeed_experts[0].gate_proj.weight.data_ptr() == w1c[0].data_ptr()
+        assert not ex._external
