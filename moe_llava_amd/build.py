@@ -30,12 +30,39 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
-    if not force and not needs_build():
+def build_library(force: bool = False, verbose: bool = True, extra_flags=(), jobs: int = 0) -> str:
+    """Compile every source to an object file (in parallel, only the stale ones unless ``force``) and link them."""
+    if not force and not needs_build() and not extra_flags:
         return LIB_PATH
-    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", *extra_flags,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = hipcc_path()
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    common = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    common.append(os.path.join(os.path.dirname(PKG_DIR), "include", "moe_gfx950.h"))
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function", *extra_flags]
+    stamp = os.path.join(objdir, "flags.txt")
+    flag_text = " ".join(flags)
+    if not os.path.exists(stamp) or open(stamp).read() != flag_text:
+        force = True
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        deps = [path, *common]
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
+            cmd = [hipcc, *flags, "-c", path, "-o", obj]
+            if verbose:
+                print("[moe_llava_amd.build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    jobs = jobs or min(len(SOURCES), int(os.environ.get("MAX_JOBS", "0")) or os.cpu_count() or 4, 8)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    with open(stamp, "w") as f:
+        f.write(flag_text)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB_PATH]
     if verbose:
         print("[moe_llava_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

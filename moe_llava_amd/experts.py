@@ -87,6 +87,15 @@ def _is_foreign_view(p: Tensor, mine) -> bool:
     return p.storage_offset() != 0 or st.nbytes() > p.numel() * p.element_size()
 
 
+def _contiguous_state_dict(module, state_dict, prefix, local_metadata):
+    """state_dict() hands out the parameters as they are: views into the packed buffers.  Those are contiguous except
+    fc2 weights of an expert width that is not a multiple of 64 (RePaMLP after reparam(): ``w2[i, :, :I]`` with a padded
+    row stride), which safetensors and ``Tensor.view`` consumers reject: hand out a contiguous copy of those."""
+    for k, v in list(state_dict.items()):
+        if k.startswith(prefix) and isinstance(v, Tensor) and not v.is_contiguous():
+            state_dict[k] = v.contiguous()
+
+
 def describe_expert(e: nn.Module) -> ExpertSpec:
     for fn in _ADAPTERS + [_adapt_builtin]:
         spec = fn(e)
@@ -113,6 +122,7 @@ class Experts(nn.Module):
         self._external: bool = False
         #: SwiGLU channels >= n_gated skip the SiLU (RePaMLP experts); -1 = ordinary experts.  Refreshed per forward.
         self.n_gated: int = -1
+        self._register_state_dict_hook(_contiguous_state_dict)
 
     # ---- packed weights ----------------------------------------------------------------------
     def _specs(self) -> List[ExpertSpec]:

@@ -284,6 +284,23 @@ def run(rank: int, world: int, port: int, mode: str, kind: str, result_dir: str)
             assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
         else:
             assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-3)
+        if mode == "gpu":
+            # the EP = 2 output DIRECTLY against the literal dense-mask oracle (all E experts on the CPU, same injected
+            # logits): routing is per rank and an expert is the same function wherever it runs, so upstream's EP output
+            # for this rank's tokens is the ep_size = 1 oracle's
+            from oracle import ds_moe_literal as lit
+            from oracle.expert_mlps import PhiMLPRef, StableLMMLPRef
+            from tests._parity import assert_out_close
+            ref = lit.MoERef(M, (StableLMMLPRef if kind == "stablelm" else PhiMLPRef)(M, I).to(torch.bfloat16),
+                             num_experts=E, ep_size=1, k=2, capacity_factor=1.0, eval_capacity_factor=2.0, min_capacity=0,
+                             top2_2nd_expert_sampling=False)
+            ref.load_state_dict({k: v.cpu() for k, v in full.state_dict().items()}, strict=True)
+            ref.train()
+            ref.deepspeed_moe.gate.logits_override = part.deepspeed_moe.gate.last_logits.cpu()
+            with torch.no_grad():
+                r_out, r_laux, r_cnt = ref(x.cpu())
+            assert torch.equal(cnt.cpu(), r_cnt) and abs(float(l_aux) - float(r_laux)) <= 1e-5
+            assert_out_close(f"EP=2 rank {rank} ({kind}) vs literal oracle", got.cpu(), r_out)
         # ---- pipelined exchange (3 chunks, odd on purpose): same rows, same results ----
         os.environ["MOE_EP_CHUNKS"] = "3"
         try:

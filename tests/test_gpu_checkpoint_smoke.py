@@ -144,3 +144,58 @@ def test_convert_save_reload_hook_and_run():
         for k in [k for k in sys.modules if k == "deepspeed" or k.startswith("deepspeed.")]:
             del sys.modules[k]
         sys.modules.update(saved_mods)
+
+
+@pytest.mark.parametrize("kind", ["stablelm", "repa176"])
+def test_save_and_reload_after_the_first_forward(kind, tmp_path):
+    """Real checkpoints are written AFTER forwards, when every expert parameter is a view into one shared packed storage
+    (and, for a RePaMLP width that is not a multiple of 64, ``down_proj.weight`` a strided view): torch.save and
+    safetensors must both round-trip every key, and the reloaded block must compute the same output."""
+    import moe_llava_amd
+    import safetensors.torch as st
+    from moe_llava_amd.expert_mlps import RePaMLP, StableLMMLP
+    torch.manual_seed(11)
+    if kind == "stablelm":
+        proto = StableLMMLP(M, I)
+    else:
+        proto = RePaMLP(M, 200, "stablelm")
+        proto.adjust_gated_ratio(0.88)                       # reparam() keeps int(200 * 0.88) = 176 channels
+    kw = dict(num_experts=E, k=2, capacity_factor=1.5, eval_capacity_factor=2.0, min_capacity=0,
+              top2_2nd_expert_sampling=False)
+
+    def build():
+        m = moe_llava_amd.MoE(M, copy.deepcopy(proto).to(torch.bfloat16), **kw)
+        if kind != "stablelm":
+            for e in m.deepspeed_moe.experts.deepspeed_experts:
+                e.reparam()
+        return m
+
+    moe = build()
+    for p in moe.deepspeed_moe.experts.parameters():
+        p.data.normal_(0, 0.05)
+    moe = moe.to(DEV).eval()
+    x = torch.randn(2, 50, M).to(torch.bfloat16).to(DEV)
+    with torch.no_grad():
+        want, _, _ = moe(x)                                  # first forward: parameters become views
+    sd = moe.state_dict()
+    if kind != "stablelm":                                   # the strided view itself is what the kernel reads
+        assert not moe.deepspeed_moe.experts.deepspeed_experts[1].down_proj.weight.is_contiguous()
+    assert all(v.is_contiguous() for v in sd.values())
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    via_torch = torch.load(buf, weights_only=True)
+    path = str(tmp_path / "moe.safetensors")
+    st.save_file({k: v for k, v in sd.items()}, path)
+    via_st = st.load_file(path)
+    for back in (via_torch, via_st):
+        assert set(back) == set(sd)
+        for k, v in sd.items():
+            assert torch.equal(back[k].cpu(), v.cpu()), k
+        fresh = build()
+        res = fresh.load_state_dict(back, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        fresh = fresh.to(DEV).eval()
+        with torch.no_grad():
+            got, _, _ = fresh(x)
+        assert torch.equal(got, want)
