@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 4
+#define MOE_ABI_VERSION 5
 
 /* activation / expert-MLP form of moe_expert_ffn_fwd */
 #define MOE_ACT_SWIGLU   0 /* h = silu(Wa x) * (Wb x); W1 = [Wa ; Wb] ([2I, M]).  StableLM: Wa=gate_proj, Wb=up_proj
@@ -94,6 +94,24 @@ int moe_routing_top2_fwd_dseed(const float *logits, uint64_t *noise_seed_dev, in
                                int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
                                int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets,
                                int32_t *perm, float *l_aux, void *workspace, size_t ws_bytes, void *stream);
+
+/* moe_routing_top2_fwd_noalloc: moe_routing_top2_fwd without the workspace argument, for callers that cannot allocate
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the
+ * reference or upstream (there every torch op allocates).  The kernels' scratch (per-block histograms, gate sums, scan
+ * results: what `workspace` holds above) lives in a device array built into the library,
+ * MOE_ROUTING_NOALLOC_SCRATCH_BYTES per GPU the library runs on, held until the process ends.  The call allocates and
+ * frees nothing and calls no allocating library routine; the caller still passes every input and output.
+ *   - S, E beyond what the array holds (moe_routing_workspace_bytes(S, E) > MOE_ROUTING_NOALLOC_SCRATCH_BYTES, e.g. more
+ *     than ~2.7 M tokens at E = 8) return MOE_ERR_WORKSPACE and launch nothing;
+ *   - all calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
+ *     serialise them or use moe_routing_top2_fwd with separate workspaces;
+ *   - the first call on a device looks the array's device address up (hipGetSymbolAddress): make it outside a capture.
+ * Outputs are bit-identical to moe_routing_top2_fwd's. */
+#define MOE_ROUTING_NOALLOC_SCRATCH_BYTES (1u << 20)
+int moe_routing_top2_fwd_noalloc(const float *logits, const float *noise, uint64_t noise_seed, int S, int E, int capacity,
+                                 int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight,
+                                 int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets,
+                                 int32_t *perm, float *l_aux, void *stream);
 
 /* moe_routing_top1_fwd: index form of upstream top1gating (MoE(k=1), reachable through
  * moellava/train/train.py:87-93 `top_k_experts` in {1,2}).

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # MOE_GFX950_LIB points the loader at another build of the same ABI (kernel A/B experiments, tools/variants)
 LIB_PATH = os.environ.get("MOE_GFX950_LIB") or os.path.join(_PKG, "libmoe_gfx950.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # (name, restype, argtypes) -- must mirror include/moe_gfx950.h exactly
 _SIGNATURES = [
@@ -28,6 +28,9 @@ _SIGNATURES = [
     ("moe_routing_top2_fwd_dseed", c_int,
      [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("moe_routing_top2_fwd_noalloc", c_int,
+     [c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+      c_void_p, c_void_p, c_void_p, c_void_p]),
     ("moe_routing_top1_workspace_bytes", c_size_t, [c_int, c_int]),
     ("moe_routing_top1_fwd", c_int,
      [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

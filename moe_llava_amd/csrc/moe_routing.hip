@@ -8,6 +8,9 @@
 // LDS holds the per-wave histograms, one small single-block kernel scans the per-block histograms.
 #include "moe_common.h"
 
+#include <atomic>
+#include <mutex>
+
 namespace moe {
 
 static thread_local char g_err[512];
@@ -710,6 +713,61 @@ extern "C" int moe_routing_top2_fwd_dseed(const float *logits, uint64_t *noise_s
         return fail(MOE_ERR_ARG, "moe_routing_top2_fwd_dseed: noise_seed_dev must be a non-null, 8-byte aligned device pointer");
     return routing_top2_launch(logits, nullptr, 0, noise_seed_dev, S, E, capacity, drop_tokens, expert_idx, slot, weight,
                                exp_counts, kept_counts, expert_offsets, perm, l_aux, workspace, ws_bytes, stream);
+}
+
+// ---- the entry point that allocates nothing and takes no workspace -----------------------------------------------------
+// moe_routing_top2_fwd with the kernels' scratch (per-block histograms, gate sums, scan results) in a file-scope device
+// array instead of a caller-provided workspace: for callers that cannot allocate (HIP graph capture, serving loops,
+// harnesses that forbid hipMalloc).  `scratch` below is a host-side stand-in, not a device address: the address each GPU
+// holds its copy at comes from hipGetSymbolAddress, once per device, and only that pointer is handed to the kernels.
+namespace {
+constexpr size_t STATIC_SCRATCH_BYTES = MOE_ROUTING_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+void *g_scratch_ptr[MAX_DEVICES];             // per device: its own copy of the array, at its own address
+std::atomic<int> g_scratch_state[MAX_DEVICES];  // 0 = not looked up, 2 = ready
+std::mutex g_scratch_mutex;
+
+// device address of `scratch` on the current device (looked up on the first call on that device)
+int static_scratch(void **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, "moe_routing_top2_fwd_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(MOE_ERR_ARG, "moe_routing_top2_fwd_noalloc: device %d out of range", dev);
+    if (g_scratch_state[dev].load(std::memory_order_acquire) != 2) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (g_scratch_state[dev].load(std::memory_order_relaxed) != 2) {
+            void *ptr = nullptr;
+            e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !ptr)
+                return fail(e != hipSuccess ? (int)e : MOE_ERR_ARG, "moe_routing_top2_fwd_noalloc: hipGetSymbolAddress: %s",
+                            hipGetErrorString(e));
+            g_scratch_ptr[dev] = ptr;
+            g_scratch_state[dev].store(2, std::memory_order_release);
+        }
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" int moe_routing_top2_fwd_noalloc(const float *logits, const float *noise, uint64_t noise_seed, int S, int E,
+                                            int capacity, int drop_tokens, int32_t *expert_idx, int32_t *slot,
+                                            float *weight, int64_t *exp_counts, int32_t *kept_counts,
+                                            int32_t *expert_offsets, int32_t *perm, float *l_aux, void *stream) {
+    if (S < 1 || E < 2 || E > 64)
+        return fail(MOE_ERR_SHAPE, "moe_routing_top2_fwd_noalloc: need S>=1 and 2<=E<=64 (S=%d E=%d)", S, E);
+    const size_t need = carve(nullptr, S, E).total;
+    if (need > STATIC_SCRATCH_BYTES)
+        return fail(MOE_ERR_WORKSPACE,
+                    "moe_routing_top2_fwd_noalloc: S=%d tokens x E=%d experts need %zu bytes of scratch, the built-in array "
+                    "holds %zu; use moe_routing_top2_fwd with a caller-provided workspace", S, E, need, STATIC_SCRATCH_BYTES);
+    void *ptr = nullptr;
+    const int rc = static_scratch(&ptr);
+    if (rc) return rc;
+    // every word of the scratch a launch reads was written by an earlier kernel of the same call: nothing to clear
+    return routing_top2_launch(logits, noise, noise_seed, nullptr, S, E, capacity, drop_tokens, expert_idx, slot, weight,
+                               exp_counts, kept_counts, expert_offsets, perm, l_aux, ptr, STATIC_SCRATCH_BYTES, stream);
 }
 
 extern "C" int moe_gather_rows_fwd(const void *src, const int32_t *gather, int gather_shift, const int32_t *n_rows_dev,

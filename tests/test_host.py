@@ -33,7 +33,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.moe_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.moe_abi_version() == _lib.ABI_VERSION == 5
     assert lib.moe_routing_workspace_bytes(22528, 4) > 0
 
 
