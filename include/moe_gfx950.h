@@ -28,7 +28,22 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 5
+#define MOE_ABI_VERSION 6
+
+/* Element type of the 16-bit activations, expert weights and biases of a forward call (`dtype` arguments below).
+ * bf16 is what the reference trains and serves with (--bf16); fp16 is what its inference loader builds the model in
+ * (moellava/model/builder.py:70 torch_dtype=torch.float16, :475 model.to(torch.float16); serve/cli.py:67-69).  The
+ * kernels compute in fp32 (v_mfma_f32_16x16x32_bf16 / _f16, same rate) and round to `dtype` exactly where the
+ * reference's 16-bit modules do.  The backward entry points (*_bwd, *_train) are bf16 only: the reference trains in
+ * bf16. */
+#define MOE_DTYPE_BF16 0
+#define MOE_DTYPE_F16  1
+/* type of the gate weight wg ([E,M]): fp32, or the same 16-bit type as the activations (a model cast with
+ * .to(torch.float16) / .to(torch.bfloat16) carries its gate in that type; upstream computes the logits from
+ * wg.weight.float() either way) */
+#define MOE_WG_F32  0
+#define MOE_WG_BF16 1
+#define MOE_WG_F16  2
 
 /* activation / expert-MLP form of moe_expert_ffn_fwd */
 #define MOE_ACT_SWIGLU   0 /* h = silu(Wa x) * (Wb x); W1 = [Wa ; Wb] ([2I, M]).  StableLM: Wa=gate_proj, Wb=up_proj
@@ -51,11 +66,11 @@ const char *moe_last_error(void);
  * moellava/model/language_model/llava_stablelm_moe.py:163 via MoE.forward.
  *
  * moe_gate_logits_fwd: logits[s,e] = sum_m float(x[s,m]) * float(wg[e,m])  (fp32 accumulate).
- *   x  [S,M] bf16 row-major (row stride M), M % 8 == 0, E <= 64.
- *   wg [E,M] fp32 (wg_is_bf16 = 0) or bf16 (1).
+ *   x  [S,M] bf16 or fp16 (dtype = MOE_DTYPE_*), row-major (row stride M), M % 8 == 0, E <= 64.
+ *   wg [E,M] of type wg_dtype = MOE_WG_F32, or MOE_WG_BF16 / MOE_WG_F16 matching dtype.
  */
-int moe_gate_logits_fwd(const void *x_bf16, const void *wg, int wg_is_bf16, float *logits,
-                        int S, int M, int E, void *stream);
+int moe_gate_logits_fwd(const void *x, const void *wg, int wg_dtype, float *logits,
+                        int S, int M, int E, int dtype, void *stream);
 
 /* bytes of workspace moe_routing_top2_fwd needs for S tokens and E experts */
 size_t moe_routing_workspace_bytes(int S, int E);
@@ -139,6 +154,8 @@ int moe_routing_top1_fwd(const float *logits, const float *noise, uint64_t noise
  * group_offsets[g+1]) and uses expert weights number (g % n_experts_local).
  *
  *   act          MOE_ACT_*
+ *   dtype        MOE_DTYPE_BF16 / MOE_DTYPE_F16: element type of a, w1, b1, w2, b2, h_ws, y ("bf16" below reads as
+ *                "dtype"); the rounding points are those of the reference's modules run in that dtype
  *   a            source rows, bf16, row stride lda elements
  *   gather       NULL: compact row p reads a[p];  else compact row p reads a[gather[p] >> gather_shift]
  *                (gather = perm of moe_routing_top2_fwd, gather_shift = 1)
@@ -160,7 +177,7 @@ int moe_routing_top1_fwd(const float *logits, const float *noise, uint64_t noise
 int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                        const void *w1, const void *b1, const void *w2, const void *b2,
                        const int32_t *group_offsets, int G, int n_experts_local, int max_rows,
-                       int M, int I, int n_gated, void *h_ws, void *y, void *stream);
+                       int M, int I, int n_gated, void *h_ws, void *y, int dtype, void *stream);
 
 /* epilogues of moe_grouped_gemm_fwd */
 #define MOE_EPI_PLAIN    0 /* out = bf16(acc + bias)                                  (fc2 / down_proj / c_proj) */
@@ -177,10 +194,10 @@ int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gathe
 int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                          const void *w, const void *bias, const int32_t *group_offsets, int G,
                          int n_experts_local, int max_rows, int K, int N, int n_gated, void *out, int64_t ldo,
-                         void *stream);
+                         int dtype, void *stream);
 
 /* moe_gather_rows_fwd: dst[p] = src[gather[p] >> gather_shift] for p < *n_rows_dev (device int32),
- * rows of M bf16.  Builds the expert-sorted send buffer of the expert-parallel all-to-all
+ * rows of M 16-bit elements (a copy: bf16 and fp16 alike, hence no dtype argument).  Builds the expert-sorted send buffer of the expert-parallel all-to-all
  * (replaces the dispatch einsum in front of _AllToAll). */
 int moe_gather_rows_fwd(const void *src, const int32_t *gather, int gather_shift,
                         const int32_t *n_rows_dev, int max_rows, int M, void *dst, void *stream);
@@ -188,9 +205,10 @@ int moe_gather_rows_fwd(const void *src, const int32_t *gather, int gather_shift
 /* moe_combine_fwd: out[s] = bf16( float(bf16(w[s,0])) * y[pos(s,0)] + float(bf16(w[s,1])) * y[pos(s,1)] ),
  * pos(s,j) = expert_offsets[expert_idx[s,j]] + slot[s,j]; a dropped choice contributes 0.
  * Replaces einsum("sec,ecm->sm", combine_weights.type_as(x), expert_output).
- * out [S,M] bf16 is fully overwritten.  M % 8 == 0.  top_k = 1 or 2 (columns of the [S,top_k] arrays). */
+ * out [S,M] is fully overwritten.  M % 8 == 0.  top_k = 1 or 2 (columns of the [S,top_k] arrays).  y and out are of
+ * type dtype and the weights are rounded to it first (fp16: "bf16(" above reads "fp16("). */
 int moe_combine_fwd(const void *y, const int32_t *expert_idx, const int32_t *slot, const float *weight,
-                    const int32_t *expert_offsets, int S, int M, int top_k, void *out, void *stream);
+                    const int32_t *expert_offsets, int S, int M, int top_k, void *out, int dtype, void *stream);
 
 /* moe_block_top2_fwd: the whole block on one GPU in one call -- moe_gate_logits_fwd, moe_routing_top2_fwd,
  * moe_expert_ffn_fwd (rows gathered through perm, one group per expert, max_rows = min(2S, E*capacity) or 2S without
@@ -198,21 +216,21 @@ int moe_combine_fwd(const void *y, const int32_t *expert_idx, const int32_t *slo
  * (h_ws [max_rows, I], y [max_rows, M], out [S, M]).  Replaces MOELayer.forward for ep_size == 1;
  * a decode step's host cost is dominated by the number of calls, hence this one.  For S <= 64 and E <= 8 the gate GEMV
  * and the routing run as one launch (same arithmetic, bit-identical logits and routing). */
-int moe_block_top2_fwd(const void *x_bf16, const void *wg, int wg_is_bf16, float *logits, const float *noise,
+int moe_block_top2_fwd(const void *x, const void *wg, int wg_dtype, float *logits, const float *noise,
                        uint64_t noise_seed, int S, int M, int E, int I, int act, int capacity, int drop_tokens,
                        int n_gated, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                        int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
                        void *routing_ws, size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2,
-                       const void *b2, void *h_ws, void *y, void *out, void *stream);
+                       const void *b2, void *h_ws, void *y, void *out, int dtype, void *stream);
 
 /* moe_block_top2_fwd_dseed: moe_block_top2_fwd with the routing of moe_routing_top2_fwd_dseed (seed in device memory,
  * advanced by the kernel): the form a HIP graph of a decode step captures.  S <= 4096, E <= 16. */
-int moe_block_top2_fwd_dseed(const void *x_bf16, const void *wg, int wg_is_bf16, float *logits, uint64_t *noise_seed_dev,
+int moe_block_top2_fwd_dseed(const void *x, const void *wg, int wg_dtype, float *logits, uint64_t *noise_seed_dev,
                              int S, int M, int E, int I, int act, int capacity, int drop_tokens, int n_gated,
                              int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                              int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
                              void *routing_ws, size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2,
-                             const void *b2, void *h_ws, void *y, void *out, void *stream);
+                             const void *b2, void *h_ws, void *y, void *out, int dtype, void *stream);
 
 /* ---- backward ---------------------------------------------------------------
  * Upstream has no hand-written backward: torch autograd differentiates top2gating, the two einsums, _AllToAll

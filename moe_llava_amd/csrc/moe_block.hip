@@ -7,7 +7,7 @@
 
 using namespace moe;
 
-static int block_top2(const void *x, const void *wg, int wg_is_bf16, float *logits, const float *noise, uint64_t noise_seed,
+static int block_top2(const void *x, int dtype, const void *wg, int wg_dtype, float *logits, const float *noise, uint64_t noise_seed,
                       uint64_t *noise_seed_dev, int S, int M, int E, int I, int act, int capacity, int drop_tokens,
                       int n_gated, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                       int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux, void *routing_ws,
@@ -19,11 +19,11 @@ static int block_top2(const void *x, const void *wg, int wg_is_bf16, float *logi
     int rc;
     if (gate_route_small_applies(S, E) && !getenv("MOE_NO_GATE_ROUTE_FUSION")) {
         // decode step: gate GEMV + routing in one launch (bit-identical logits and routing)
-        rc = launch_gate_route_small(x, wg, wg_is_bf16, logits, noise, noise_seed, noise_seed_dev, S, M, E, capacity,
+        rc = launch_gate_route_small(x, dtype, wg, wg_dtype, logits, noise, noise_seed, noise_seed_dev, S, M, E, capacity,
                                      drop_tokens, expert_idx, slot, weight, exp_counts, kept_counts, expert_offsets, perm,
                                      l_aux, stream);
     } else {
-        rc = moe_gate_logits_fwd(x, wg, wg_is_bf16, logits, S, M, E, stream);
+        rc = moe_gate_logits_fwd(x, wg, wg_dtype, logits, S, M, E, dtype, stream);
         if (rc) return rc;
         rc = noise_seed_dev
                  ? moe_routing_top2_fwd_dseed(logits, noise_seed_dev, S, E, capacity, drop_tokens, expert_idx, slot, weight,
@@ -36,34 +36,34 @@ static int block_top2(const void *x, const void *wg, int wg_is_bf16, float *logi
     if (rc) return rc;
     if (max_rows > 0) {
         rc = moe_expert_ffn_fwd(act, x, M, perm, 1, w1, b1, w2, b2, expert_offsets, E, E, max_rows, M, I, n_gated, h_ws, y,
-                                stream);
+                                dtype, stream);
         if (rc) return rc;
     }
-    return moe_combine_fwd(y, expert_idx, slot, weight, expert_offsets, S, M, 2, out, stream);
+    return moe_combine_fwd(y, expert_idx, slot, weight, expert_offsets, S, M, 2, out, dtype, stream);
 }
 
-extern "C" int moe_block_top2_fwd(const void *x, const void *wg, int wg_is_bf16, float *logits, const float *noise,
+extern "C" int moe_block_top2_fwd(const void *x, const void *wg, int wg_dtype, float *logits, const float *noise,
                                   uint64_t noise_seed, int S, int M, int E, int I, int act, int capacity, int drop_tokens,
                                   int n_gated, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                                   int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
                                   void *routing_ws, size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2,
-                                  const void *b2, void *h_ws, void *y, void *out, void *stream) {
-    return block_top2(x, wg, wg_is_bf16, logits, noise, noise_seed, nullptr, S, M, E, I, act, capacity, drop_tokens, n_gated,
+                                  const void *b2, void *h_ws, void *y, void *out, int dtype, void *stream) {
+    return block_top2(x, dtype, wg, wg_dtype, logits, noise, noise_seed, nullptr, S, M, E, I, act, capacity, drop_tokens, n_gated,
                       expert_idx, slot, weight, exp_counts, kept_counts, expert_offsets, perm, l_aux, routing_ws,
                       routing_ws_bytes, w1, b1, w2, b2, h_ws, y, out, stream);
 }
 
 // The same with the Gumbel seed in device memory, read and advanced by the routing kernel: every launch argument is
 // then constant from call to call, so a captured HIP graph of the step can be replayed (decode loops).
-extern "C" int moe_block_top2_fwd_dseed(const void *x, const void *wg, int wg_is_bf16, float *logits,
+extern "C" int moe_block_top2_fwd_dseed(const void *x, const void *wg, int wg_dtype, float *logits,
                                         uint64_t *noise_seed_dev, int S, int M, int E, int I, int act, int capacity,
                                         int drop_tokens, int n_gated, int32_t *expert_idx, int32_t *slot, float *weight,
                                         int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm,
                                         float *l_aux, void *routing_ws, size_t routing_ws_bytes, const void *w1,
                                         const void *b1, const void *w2, const void *b2, void *h_ws, void *y, void *out,
-                                        void *stream) {
+                                        int dtype, void *stream) {
     if (!noise_seed_dev) return fail(MOE_ERR_ARG, "moe_block_top2_fwd_dseed: null noise_seed_dev");
-    return block_top2(x, wg, wg_is_bf16, logits, nullptr, 0, noise_seed_dev, S, M, E, I, act, capacity, drop_tokens, n_gated,
+    return block_top2(x, dtype, wg, wg_dtype, logits, nullptr, 0, noise_seed_dev, S, M, E, I, act, capacity, drop_tokens, n_gated,
                       expert_idx, slot, weight, exp_counts, kept_counts, expert_offsets, perm, l_aux, routing_ws,
                       routing_ws_bytes, w1, b1, w2, b2, h_ws, y, out, stream);
 }

@@ -67,6 +67,73 @@ __device__ __forceinline__ uint4 pack8(const float *f) {
     return o;
 }
 
+// ---- element type of the activations / expert weights: bf16 (training, --bf16 serving) or fp16 (the reference's
+//      inference loader, moellava/model/builder.py:70,475).  Elt<DT> holds every conversion and rounding point, so a
+//      kernel templated on DT rounds to the tensor dtype exactly where torch's 16-bit modules do. ----
+enum { DT_BF16 = MOE_DTYPE_BF16, DT_F16 = MOE_DTYPE_F16 };
+typedef __attribute__((ext_vector_type(8))) __bf16 moe_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 moe_f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float moe_f32x4_t;
+typedef _Float16 moe_f16x2_t __attribute__((ext_vector_type(2)));
+
+template <int DT>
+struct Elt;
+template <>
+struct Elt<DT_BF16> {
+    typedef moe_bf16x8_t frag_t;
+    static __device__ __forceinline__ float to_f(bf16_t b) { return bf2f(b); }
+    static __device__ __forceinline__ bf16_t from_f(float f) { return f2bf(f); }
+    static __device__ __forceinline__ float round(float f) { return rbf(f); }
+    static __device__ __forceinline__ unsigned pack2(float x, float y) { return pack_bf2(x, y); }
+    static __device__ __forceinline__ void unpack2(unsigned u, float &x, float &y) {
+        x = __builtin_bit_cast(float, u << 16);
+        y = __builtin_bit_cast(float, u & 0xffff0000u);
+    }
+    static __device__ __forceinline__ moe_f32x4_t mfma(frag_t a, frag_t b, moe_f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Elt<DT_F16> {
+    typedef moe_f16x8_t frag_t;
+    static __device__ __forceinline__ float to_f(bf16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+    static __device__ __forceinline__ bf16_t from_f(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+    static __device__ __forceinline__ float round(float f) { return (float)(_Float16)f; }
+    static __device__ __forceinline__ unsigned pack2(float x, float y) {
+        const moe_f32x2_t v = {x, y};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, moe_f16x2_t));  // round to nearest even
+    }
+    static __device__ __forceinline__ void unpack2(unsigned u, float &x, float &y) {
+        const moe_f16x2_t h = __builtin_bit_cast(moe_f16x2_t, u);
+        x = (float)h.x;
+        y = (float)h.y;
+    }
+    static __device__ __forceinline__ moe_f32x4_t mfma(frag_t a, frag_t b, moe_f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+// round two fp32 values to the element type and return them as fp32
+template <int DT>
+__device__ __forceinline__ void round2(float &x, float &y) {
+    Elt<DT>::unpack2(Elt<DT>::pack2(x, y), x, y);
+}
+template <int DT>
+__device__ __forceinline__ void unpack8_t(const uint4 v, float *f) {
+    Elt<DT>::unpack2(v.x, f[0], f[1]);
+    Elt<DT>::unpack2(v.y, f[2], f[3]);
+    Elt<DT>::unpack2(v.z, f[4], f[5]);
+    Elt<DT>::unpack2(v.w, f[6], f[7]);
+}
+template <int DT>
+__device__ __forceinline__ uint4 pack8_t(const float *f) {
+    uint4 o;
+    o.x = Elt<DT>::pack2(f[0], f[1]);
+    o.y = Elt<DT>::pack2(f[2], f[3]);
+    o.z = Elt<DT>::pack2(f[4], f[5]);
+    o.w = Elt<DT>::pack2(f[6], f[7]);
+    return o;
+}
+
 // ---- expert activations, evaluated the way a bf16 tensor goes through the reference's modules ----
 __device__ __forceinline__ float fast_sigmoid(float a) { return __builtin_amdgcn_rcpf(1.f + __expf(-a)); }
 __device__ __forceinline__ float fast_silu(float a) {
@@ -93,6 +160,24 @@ __device__ __forceinline__ float gelu_new_bf16(float x) {
     const float t5 = rbf(1.0f + t4);
     const float t6 = rbf(0.5f * x);
     return rbf(t6 * t5);
+}
+
+// The same two activations with the rounding points of element type DT (bf16: identical to the functions above).
+template <int DT>
+__device__ __forceinline__ bf16_t swiglu_r(float a, float b, bool gated = true) {
+    return Elt<DT>::from_f((gated ? Elt<DT>::round(fast_silu(a)) : 1.0f) * b);
+}
+template <int DT>
+__device__ __forceinline__ float gelu_new_r(float x) {
+    typedef Elt<DT> E;
+    const float p3 = E::round(x * x * x);
+    const float t1 = E::round(0.044715f * p3);
+    const float t2 = E::round(x + t1);
+    const float t3 = E::round(0.7978845608028654f * t2);
+    const float t4 = E::round(fast_tanh(t3));
+    const float t5 = E::round(1.0f + t4);
+    const float t6 = E::round(0.5f * x);
+    return E::round(t6 * t5);
 }
 
 // Backward of the activations on 8 packed elements, with the bf16 rounding points of the autograd graph of the
@@ -152,12 +237,13 @@ struct GemmParams {
     int rs;            // row tiles per super-row of the block -> tile map (moe_gemm.hip)
     const bf16_t *aux;  // EPI_DSWIGLU / EPI_DGELU: pre-activations AB [rows, ld_aux]
     long long ld_aux;
+    int dtype;          // DT_BF16 / DT_F16: element type of a, w, bias, out (16-bit raw in the pointers above)
 };
 
 // Decode-size launches (moe_gemv.hip): every group has at most SKINNY_MAX_ROWS rows.
 constexpr int SKINNY_MAX_ROWS = 64;
 bool gate_route_small_applies(int S, int E);
-int launch_gate_route_small(const void *x, const void *wg, int wg_is_bf16, float *logits, const float *noise,
+int launch_gate_route_small(const void *x, int dtype, const void *wg, int wg_dtype, float *logits, const float *noise,
                             uint64_t noise_seed, uint64_t *noise_seed_dev, int S, int M, int E, int capacity,
                             int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                             int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux, void *stream);

@@ -22,7 +22,6 @@
 
 namespace moe {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int BK = 64;  // K slice per ring slot
@@ -107,9 +106,11 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int EPI, int BM, int BNW>
+template <int DT, int EPI, int BM, int BNW>
 __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmParams p) {
     using T = Tile<EPI, BM, BNW>;
+    typedef Elt<DT> E;                    // element type of the operands and of the output (bf16 / fp16)
+    typedef typename E::frag_t bf16x8_t;  // 8 K-consecutive elements: one MFMA operand
 #ifdef GEMM_STAMPS
     const unsigned long long st_entry = stamp();
 #endif
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                     }
 #pragma unroll
                     for (int nf = 0; nf < NF; ++nf)
-                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks & 1][nf], xf[t], acc[nf][mf], 0, 0, 0);
+                        acc[nf][mf] = E::mfma(wf[ks & 1][nf], xf[t], acc[nf][mf]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #ifndef GEMM_NO_SETPRIO
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
                     for (int mf = 0; mf < MFW; ++mf)
-                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+                        acc[nf][mf] = E::mfma(wf[nf], xf[mf], acc[nf][mf]);
                 }
 #ifndef GEMM_NO_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
@@ -387,8 +388,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 if (bias && c0 < p.N_out) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        ba[j] = bf2f(bias[c0 + j]);
-                        bb[j] = bf2f(bias[p.b_row_offset + c0 + j]);
+                        ba[j] = E::to_f(bias[c0 + j]);
+                        bb[j] = E::to_f(bias[p.b_row_offset + c0 + j]);
                     }
                 }
 #pragma unroll
@@ -408,18 +409,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                             b[j] += bb[j];
                         }
                     }
-                    rbf2(a[0], a[1]); rbf2(a[2], a[3]); rbf2(b[0], b[1]); rbf2(b[2], b[3]);
+                    round2<DT>(a[0], a[1]); round2<DT>(a[2], a[3]); round2<DT>(b[0], b[1]); round2<DT>(b[2], b[3]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) sg[j] = fast_silu(a[j]);
-                    rbf2(sg[0], sg[1]); rbf2(sg[2], sg[3]);
+                    round2<DT>(sg[0], sg[1]); round2<DT>(sg[2], sg[3]);
                     if (!all_gated) {
                         // RePaMLP: torch.where(mask, silu, 1) (llava_stablelm_moe.py:636-638)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) sg[j] = (c0 + j < p.n_gated) ? sg[j] : 1.0f;
                     }
                     uint2 o;
-                    o.x = pack_bf2(sg[0] * b[0], sg[1] * b[1]);
-                    o.y = pack_bf2(sg[2] * b[2], sg[3] * b[3]);
+                    o.x = E::pack2(sg[0] * b[0], sg[1] * b[1]);
+                    o.y = E::pack2(sg[2] * b[2], sg[3] * b[3]);
                     *reinterpret_cast<uint2 *>(img + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
                 }
             }
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
                 if (bias && c0 < p.N_out) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[j] = bf2f(bias[c0 + j]);
+                    for (int j = 0; j < 4; ++j) bv[j] = E::to_f(bias[c0 + j]);
                 }
 #pragma unroll
                 for (int mf = 0; mf < MFW; ++mf) {
@@ -439,13 +440,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = acc[nf][mf][j] + bv[j];  // bf16 output of the Linear (rounded below)
                     if (EPI == EPI_GELU_NEW) {
-                        rbf2(v[0], v[1]); rbf2(v[2], v[3]);
+                        round2<DT>(v[0], v[1]); round2<DT>(v[2], v[3]);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = gelu_new_bf16(v[j]);
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_new_r<DT>(v[j]);
                     }
                     uint2 o;
-                    o.x = pack_bf2(v[0], v[1]);
-                    o.y = pack_bf2(v[2], v[3]);
+                    o.x = E::pack2(v[0], v[1]);
+                    o.y = E::pack2(v[2], v[3]);
                     *reinterpret_cast<uint2 *>(img + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
                 }
             }
@@ -571,7 +572,7 @@ static TileChoice choose_tile(int epilogue, int max_rows, int G, int N) {
     return t;
 }
 
-template <int EPI, int BM, int BNW>
+template <int DT, int EPI, int BM, int BNW>
 static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     constexpr int NC = Tile<EPI, BM, BNW>::NC;
     p.max_row_tiles = max_rows_or_neg / BM + p.G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
@@ -587,34 +588,34 @@ static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     // (measured: fc1 of config 2, 7832 tiles, -1.3 %; launches of a few rounds gain nothing and, being 256 resident
     // blocks, could no longer interleave with a second stream's launch, so they keep one block per tile)
     if (GEMM_PERSIST && BM == 256 && BNW == 256 && grid >= 4096 && !getenv("MOE_NO_PERSIST")) grid = 256;
-    hipLaunchKernelGGL((grouped_gemm_kernel<EPI, BM, BNW>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, p);
+    hipLaunchKernelGGL((grouped_gemm_kernel<DT, EPI, BM, BNW>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, p);
     return check_launch("grouped_gemm_kernel");
 }
 
-template <int EPI>
+template <int DT, int EPI>
 static int launch_gemm(GemmParams &p, int max_rows, TileChoice t, hipStream_t st) {
     if (EPI != EPI_SWIGLU && t.bnw == 64) {
         constexpr int E2 = EPI == EPI_SWIGLU ? EPI_PLAIN : EPI;  // keeps the SWIGLU x 64 combination uninstantiated
         switch (t.bm) {
-            case 256: return launch_tile<E2, 256, 64>(p, max_rows, st);
-            case 128: return launch_tile<E2, 128, 64>(p, max_rows, st);
-            case 64: return launch_tile<E2, 64, 64>(p, max_rows, st);
-            default: return launch_tile<E2, 32, 64>(p, max_rows, st);
+            case 256: return launch_tile<DT, E2, 256, 64>(p, max_rows, st);
+            case 128: return launch_tile<DT, E2, 128, 64>(p, max_rows, st);
+            case 64: return launch_tile<DT, E2, 64, 64>(p, max_rows, st);
+            default: return launch_tile<DT, E2, 32, 64>(p, max_rows, st);
         }
     }
     if (t.bnw == 128) {
         switch (t.bm) {
-            case 256: return launch_tile<EPI, 256, 128>(p, max_rows, st);
-            case 128: return launch_tile<EPI, 128, 128>(p, max_rows, st);
-            case 64: return launch_tile<EPI, 64, 128>(p, max_rows, st);
-            default: return launch_tile<EPI, 32, 128>(p, max_rows, st);
+            case 256: return launch_tile<DT, EPI, 256, 128>(p, max_rows, st);
+            case 128: return launch_tile<DT, EPI, 128, 128>(p, max_rows, st);
+            case 64: return launch_tile<DT, EPI, 64, 128>(p, max_rows, st);
+            default: return launch_tile<DT, EPI, 32, 128>(p, max_rows, st);
         }
     }
     switch (t.bm) {
-        case 256: return launch_tile<EPI, 256, 256>(p, max_rows, st);
-        case 128: return launch_tile<EPI, 128, 256>(p, max_rows, st);
-        case 64: return launch_tile<EPI, 64, 256>(p, max_rows, st);
-        default: return launch_tile<EPI, 32, 256>(p, max_rows, st);
+        case 256: return launch_tile<DT, EPI, 256, 256>(p, max_rows, st);
+        case 128: return launch_tile<DT, EPI, 128, 256>(p, max_rows, st);
+        case 64: return launch_tile<DT, EPI, 64, 256>(p, max_rows, st);
+        default: return launch_tile<DT, EPI, 32, 256>(p, max_rows, st);
     }
 }
 
@@ -644,7 +645,8 @@ extern "C" int moe_debug_read_stamps(unsigned long long *host_dst) {
 static int grouped_gemm_launch(const char *fn, int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                const void *w, const void *bias, const int32_t *group_offsets, int G, int n_experts_local,
                                int max_rows, int K, int N, int n_gated, void *out, int64_t ldo, const void *aux,
-                               int64_t ld_aux, void *stream) {
+                               int64_t ld_aux, int dtype, void *stream) {
+    if (dtype != MOE_DTYPE_BF16 && dtype != MOE_DTYPE_F16) return fail(MOE_ERR_ARG, "%s: unknown dtype %d", fn, dtype);
     int rc = gemm_args_ok(fn, a, lda, gather_shift, w, group_offsets, G, n_experts_local, max_rows, K, N, out, ldo);
     if (rc) return rc;
     if (max_rows == 0) return 0;
@@ -666,6 +668,7 @@ static int grouped_gemm_launch(const char *fn, int epilogue, const void *a, int6
     p.n_gated = (n_gated < 0 || n_gated > N) ? N : n_gated;
     p.aux = (const bf16_t *)aux;
     p.ld_aux = ld_aux;
+    p.dtype = dtype;
     hipStream_t st = (hipStream_t)stream;
     p.w_expert_stride = (epilogue == MOE_EPI_SWIGLU ? 2ll : 1ll) * N * K;
     p.bias_expert_stride = (epilogue == MOE_EPI_SWIGLU ? 2ll : 1ll) * N;
@@ -673,30 +676,39 @@ static int grouped_gemm_launch(const char *fn, int epilogue, const void *a, int6
     if (max_rows <= SKINNY_MAX_ROWS && epilogue <= MOE_EPI_GELU_NEW && !getenv("MOE_NO_SKINNY"))
         return launch_skinny_gemm(p, epilogue, max_rows, st);
     const TileChoice t = choose_tile(epilogue, max_rows, G, N);
-    if (epilogue == MOE_EPI_SWIGLU) return launch_gemm<EPI_SWIGLU>(p, max_rows, t, st);
+    if (dtype == MOE_DTYPE_F16) {  // forward epilogues only: the backward entry points are bf16
+        switch (epilogue) {
+            case MOE_EPI_SWIGLU: return launch_gemm<DT_F16, EPI_SWIGLU>(p, max_rows, t, st);
+            case MOE_EPI_GELU_NEW: return launch_gemm<DT_F16, EPI_GELU_NEW>(p, max_rows, t, st);
+            case MOE_EPI_PLAIN: return launch_gemm<DT_F16, EPI_PLAIN>(p, max_rows, t, st);
+            default: return fail(MOE_ERR_ARG, "%s: epilogue %d is bf16 only", fn, epilogue);
+        }
+    }
+    if (epilogue == MOE_EPI_SWIGLU) return launch_gemm<DT_BF16, EPI_SWIGLU>(p, max_rows, t, st);
     switch (epilogue) {
-        case MOE_EPI_GELU_NEW: return launch_gemm<EPI_GELU_NEW>(p, max_rows, t, st);
-        case EPI_DSWIGLU: return launch_gemm<EPI_DSWIGLU>(p, max_rows, t, st);
-        case EPI_DGELU: return launch_gemm<EPI_DGELU>(p, max_rows, t, st);
-        default: return launch_gemm<EPI_PLAIN>(p, max_rows, t, st);
+        case MOE_EPI_GELU_NEW: return launch_gemm<DT_BF16, EPI_GELU_NEW>(p, max_rows, t, st);
+        case EPI_DSWIGLU: return launch_gemm<DT_BF16, EPI_DSWIGLU>(p, max_rows, t, st);
+        case EPI_DGELU: return launch_gemm<DT_BF16, EPI_DGELU>(p, max_rows, t, st);
+        default: return launch_gemm<DT_BF16, EPI_PLAIN>(p, max_rows, t, st);
     }
 }
 
 extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                     const void *w, const void *bias, const int32_t *group_offsets, int G,
                                     int n_experts_local, int max_rows, int K, int N, int n_gated, void *out, int64_t ldo,
-                                    void *stream) {
+                                    int dtype, void *stream) {
     if (epilogue != MOE_EPI_PLAIN && epilogue != MOE_EPI_SWIGLU && epilogue != MOE_EPI_GELU_NEW)
         return fail(MOE_ERR_ARG, "moe_grouped_gemm_fwd: unknown epilogue %d", epilogue);
     return grouped_gemm_launch("moe_grouped_gemm_fwd", epilogue, a, lda, gather, gather_shift, w, bias, group_offsets, G,
-                               n_experts_local, max_rows, K, N, n_gated, out, ldo, nullptr, 0, stream);
+                               n_experts_local, max_rows, K, N, n_gated, out, ldo, nullptr, 0, dtype, stream);
 }
 
 extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                   const void *w1, const void *b1, const void *w2, const void *b2,
                                   const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
-                                  int n_gated, void *h_ws, void *y, void *stream) {
+                                  int n_gated, void *h_ws, void *y, int dtype, void *stream) {
     if (!h_ws || !y || !w2) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: null pointer");
+    if (dtype != MOE_DTYPE_BF16 && dtype != MOE_DTYPE_F16) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: unknown dtype %d", dtype);
     if (act != MOE_ACT_SWIGLU && act != MOE_ACT_GELU_NEW) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: unknown act %d", act);
     if (M <= 0 || I <= 0 || (M % 64) || (I % 64))
         return fail(MOE_ERR_SHAPE, "moe_expert_ffn_fwd: need M%%64==0 and I%%64==0 (M=%d I=%d)", M, I);
@@ -704,10 +716,10 @@ extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int
     int rc = gemm_args_ok("moe_expert_ffn_fwd", h_ws, I, 0, w2, group_offsets, G, n_experts_local, max_rows, I, M, y, M);
     if (rc) return rc;
     rc = moe_grouped_gemm_fwd(act == MOE_ACT_SWIGLU ? MOE_EPI_SWIGLU : MOE_EPI_GELU_NEW, a, lda, gather, gather_shift, w1, b1,
-                              group_offsets, G, n_experts_local, max_rows, M, I, n_gated, h_ws, I, stream);
+                              group_offsets, G, n_experts_local, max_rows, M, I, n_gated, h_ws, I, dtype, stream);
     if (rc) return rc;
     return moe_grouped_gemm_fwd(MOE_EPI_PLAIN, h_ws, I, nullptr, 0, w2, b2, group_offsets, G, n_experts_local, max_rows, I, M,
-                                -1, y, M, stream);
+                                -1, y, M, dtype, stream);
 }
 
 extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
@@ -725,13 +737,13 @@ extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, con
     const int N1 = act == MOE_ACT_SWIGLU ? 2 * I : I;
     // fc1 with the plain epilogue: the packed [a | b] rows of W1 give AB = [a | b] columns (bf16, bias added)
     rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, a, lda, gather, gather_shift, w1, b1, group_offsets, G, n_experts_local, max_rows,
-                              M, N1, -1, ab, N1, stream);
+                              M, N1, -1, ab, N1, MOE_DTYPE_BF16, stream);
     if (rc) return rc;
     if (max_rows == 0) return 0;
     rc = launch_act_fwd(act, (const bf16_t *)ab, group_offsets + G, max_rows, I, n_gated, (bf16_t *)h, (hipStream_t)stream);
     if (rc) return rc;
     return moe_grouped_gemm_fwd(MOE_EPI_PLAIN, h, I, nullptr, 0, w2, b2, group_offsets, G, n_experts_local, max_rows, I, M,
-                                -1, y, M, stream);
+                                -1, y, M, MOE_DTYPE_BF16, stream);
 }
 
 namespace {
@@ -801,14 +813,14 @@ extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int
     // dH = dY @ W2 never reaches HBM: the store phase of this launch turns each dH chunk into dAB with the kept
     // pre-activations (same arithmetic and rounding as act_bwd_kernel on a bf16 dH)
     if ((rc = grouped_gemm_launch(fn, act == MOE_ACT_SWIGLU ? EPI_DSWIGLU : EPI_DGELU, dy, M, nullptr, 0, ws.wt, nullptr,
-                                  group_offsets, G, El, max_rows, M, I, n_gated, ws.dab, N1, ab, N1, stream)))
+                                  group_offsets, G, El, max_rows, M, I, n_gated, ws.dab, N1, ab, N1, MOE_DTYPE_BF16, stream)))
         return rc;
     if ((rc = launch_wgrad_tn(dyp, M, (const bf16_t *)h, I, group_offsets, G, El, max_rows, M, I, (bf16_t *)dw2, st))) return rc;
     if (db2 && (rc = launch_bias_grad(dyp, group_offsets, G, El, max_rows, M, db2, st))) return rc;
     // ---- fc1: dA = dAB @ W1, dW1 = dAB^T @ A, db1 = colsum(dAB) ----
     if ((rc = launch_transpose_batched((const bf16_t *)w1, El, N1, M, ws.wt, st))) return rc;  // W1^T [El, M, N1]
     if ((rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, ws.dab, N1, nullptr, 0, ws.wt, nullptr, group_offsets, G, El, max_rows, N1,
-                                   M, -1, da_rows, M, stream)))
+                                   M, -1, da_rows, M, MOE_DTYPE_BF16, stream)))
         return rc;
     const bf16_t *xrows = (const bf16_t *)a;
     long long ldx = lda;

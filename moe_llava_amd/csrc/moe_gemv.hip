@@ -14,11 +14,11 @@
 
 namespace moe {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-__device__ __forceinline__ bf16x8_t ld16(const bf16_t *p) {
-    return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(p));
+template <int DT>
+__device__ __forceinline__ typename Elt<DT>::frag_t ld16(const bf16_t *p) {
+    return __builtin_bit_cast(typename Elt<DT>::frag_t, *reinterpret_cast<const uint4 *>(p));
 }
 
 // NW = 16-column groups per block: one X fragment load serves NW (x2 when gated) weight fragments.
@@ -36,9 +36,11 @@ struct SkinnyCfg {
     static_assert(NW == 1 || NW == 2, "column groups per block");
 };
 
-template <int EPI, int RT, int KSPLIT, int NWP>
+template <int DT, int EPI, int RT, int KSPLIT, int NWP>
 __device__ __forceinline__ void skinny_body(const GemmParams &p, int grp, int row_begin, int n_rows, int ctile, float *red) {
     using C = SkinnyCfg<EPI, NWP>;
+    typedef Elt<DT> E;
+    typedef typename E::frag_t bf16x8_t;  // 8 elements of the launch's 16-bit type
     constexpr bool GATED = C::GATED;
     constexpr int NACC = C::NACC, NW = C::NW, U = C::U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,11 +80,11 @@ __device__ __forceinline__ void skinny_body(const GemmParams &p, int grp, int ro
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int g = 0; g < NW; ++g) {
-                fw[u][0][g] = ld16(wa[g] + (s + u) * 32);
-                if (GATED) fw[u][NACC - 1][g] = ld16(wa[g] + b_off + (s + u) * 32);
+                fw[u][0][g] = ld16<DT>(wa[g] + (s + u) * 32);
+                if (GATED) fw[u][NACC - 1][g] = ld16<DT>(wa[g] + b_off + (s + u) * 32);
             }
 #pragma unroll
-            for (int t = 0; t < RT; ++t) fx[u][t] = ld16(xr[t] + (s + u) * 32);
+            for (int t = 0; t < RT; ++t) fx[u][t] = ld16<DT>(xr[t] + (s + u) * 32);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -92,22 +94,22 @@ __device__ __forceinline__ void skinny_body(const GemmParams &p, int grp, int ro
                 for (int g = 0; g < NW; ++g)
 #pragma unroll
                     for (int t = 0; t < RT; ++t)
-                        acc[h][g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[u][h][g], fx[u][t], acc[h][g][t], 0, 0, 0);
+                        acc[h][g][t] = E::mfma(fw[u][h][g], fx[u][t], acc[h][g][t]);
     }
     for (; s < k_hi; ++s) {
         bf16x8_t fx[RT];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) fx[t] = ld16(xr[t] + s * 32);
+        for (int t = 0; t < RT; ++t) fx[t] = ld16<DT>(xr[t] + s * 32);
 #pragma unroll
         for (int g = 0; g < NW; ++g) {
-            const bf16x8_t fa = ld16(wa[g] + s * 32);
+            const bf16x8_t fa = ld16<DT>(wa[g] + s * 32);
 #pragma unroll
-            for (int t = 0; t < RT; ++t) acc[0][g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fx[t], acc[0][g][t], 0, 0, 0);
+            for (int t = 0; t < RT; ++t) acc[0][g][t] = E::mfma(fa, fx[t], acc[0][g][t]);
             if (GATED) {
-                const bf16x8_t fb = ld16(wa[g] + b_off + s * 32);
+                const bf16x8_t fb = ld16<DT>(wa[g] + b_off + s * 32);
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
-                    acc[NACC - 1][g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fx[t], acc[NACC - 1][g][t], 0, 0, 0);
+                    acc[NACC - 1][g][t] = E::mfma(fb, fx[t], acc[NACC - 1][g][t]);
             }
         }
     }
@@ -144,12 +146,12 @@ __device__ __forceinline__ void skinny_body(const GemmParams &p, int grp, int ro
                     unsigned short hv[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float a = rbf(sa[j] + (bias ? bf2f(bias[c0 + j]) : 0.f));  // bf16 output of the Linear
+                        const float a = E::round(sa[j] + (bias ? E::to_f(bias[c0 + j]) : 0.f));  // 16-bit output of the Linear
                         if (GATED) {
-                            const float b = rbf(sb[j] + (bias ? bf2f(bias[p.b_row_offset + c0 + j]) : 0.f));
-                            hv[j] = swiglu_bf16(a, b, c0 + j < p.n_gated);
+                            const float b = E::round(sb[j] + (bias ? E::to_f(bias[p.b_row_offset + c0 + j]) : 0.f));
+                            hv[j] = swiglu_r<DT>(a, b, c0 + j < p.n_gated);
                         } else {
-                            hv[j] = (EPI == EPI_GELU_NEW) ? f2bf(gelu_new_bf16(a)) : f2bf(a);
+                            hv[j] = (EPI == EPI_GELU_NEW) ? E::from_f(gelu_new_r<DT>(a)) : E::from_f(a);
                         }
                     }
                     uint2 o;
@@ -162,7 +164,7 @@ __device__ __forceinline__ void skinny_body(const GemmParams &p, int grp, int ro
     }
 }
 
-template <int EPI, int KSPLIT, int NWP>
+template <int DT, int EPI, int KSPLIT, int NWP>
 __global__ __launch_bounds__(64 * KSPLIT) void skinny_gemm_kernel(const GemmParams p) {
     using C = SkinnyCfg<EPI, NWP>;
     __shared__ __attribute__((aligned(16))) float red[KSPLIT * C::NACC * C::NW * 64 * 4];  // KSPLIT x 4 KiB
@@ -172,10 +174,10 @@ __global__ __launch_bounds__(64 * KSPLIT) void skinny_gemm_kernel(const GemmPara
     const int n = e - b;
     if (n <= 0) return;                      // idle expert: its weights are not read (uniform for the block)
     switch ((min(n, SKINNY_MAX_ROWS) + 15) >> 4) {
-        case 1: skinny_body<EPI, 1, KSPLIT, NWP>(p, grp, b, min(n, 16), ctile, red); break;
-        case 2: skinny_body<EPI, 2, KSPLIT, NWP>(p, grp, b, min(n, 32), ctile, red); break;
-        case 3: skinny_body<EPI, 3, KSPLIT, NWP>(p, grp, b, min(n, 48), ctile, red); break;
-        default: skinny_body<EPI, 4, KSPLIT, NWP>(p, grp, b, min(n, 64), ctile, red); break;
+        case 1: skinny_body<DT, EPI, 1, KSPLIT, NWP>(p, grp, b, min(n, 16), ctile, red); break;
+        case 2: skinny_body<DT, EPI, 2, KSPLIT, NWP>(p, grp, b, min(n, 32), ctile, red); break;
+        case 3: skinny_body<DT, EPI, 3, KSPLIT, NWP>(p, grp, b, min(n, 48), ctile, red); break;
+        default: skinny_body<DT, EPI, 4, KSPLIT, NWP>(p, grp, b, min(n, 64), ctile, red); break;
     }
 }
 
@@ -208,7 +210,11 @@ int launch_skinny_gemm(const GemmParams &p0, int epilogue, int max_rows, hipStre
         if (v == 1 || v == 2 || v == 4 || v == 8) ks = v;
     }
     const dim3 g((unsigned)grid), b(64 * ks);
-#define LAUNCH_SK(E_, K_, N_) hipLaunchKernelGGL((skinny_gemm_kernel<E_, K_, N_>), g, b, 0, st, p)
+#define LAUNCH_SK(E_, K_, N_)                                                                       \
+    do {                                                                                            \
+        if (p.dtype == DT_F16) hipLaunchKernelGGL((skinny_gemm_kernel<DT_F16, E_, K_, N_>), g, b, 0, st, p);  \
+        else hipLaunchKernelGGL((skinny_gemm_kernel<DT_BF16, E_, K_, N_>), g, b, 0, st, p);          \
+    } while (0)
 #define LAUNCH_SK_KS(E_, N_)                               \
     switch (ks) {                                          \
         case 8: LAUNCH_SK(E_, 8, N_); break;               \

@@ -42,7 +42,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // ------------------------------------------------------------------------------------------------
 // rows row0 .. row0 + R - 1 (clamped to S - 1, stored only when < S) x E experts by ONE wave.  The result of a row
 // does not depend on R or on which wave computes it: a fixed per-lane fmaf chain over M, then the wave butterfly.
-template <int EMAX, int R, bool WG_BF16>
+// DT = element type of x; WG16: wg has that same 16-bit type (otherwise fp32).
+template <int EMAX, int R, bool WG16, int DT>
 __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const void *__restrict__ wg,
                                           float *__restrict__ logits, int S, int M, int E, int row0, int lane) {
     float acc[R][EMAX];
@@ -57,26 +58,14 @@ __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const vo
         for (int r = 0; r < R; ++r) {
             int row = row0 + r;
             if (row > S - 1) row = S - 1;
-            const uint4 v = *reinterpret_cast<const uint4 *>(x + (size_t)row * M + m0);
-            const unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                xf[r][2 * j] = __builtin_bit_cast(float, u[j] << 16);
-                xf[r][2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xffff0000u);
-            }
+            unpack8_t<DT>(*reinterpret_cast<const uint4 *>(x + (size_t)row * M + m0), xf[r]);
         }
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) {
             if (e < E) {
                 float w[8];
-                if (WG_BF16) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(wg) + (size_t)e * M + m0);
-                    const unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        w[2 * j] = __builtin_bit_cast(float, u[j] << 16);
-                        w[2 * j + 1] = __builtin_bit_cast(float, u[j] & 0xffff0000u);
-                    }
+                if (WG16) {
+                    unpack8_t<DT>(*reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(wg) + (size_t)e * M + m0), w);
                 } else {
                     const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(wg) + (size_t)e * M + m0);
                     const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(wg) + (size_t)e * M + m0 + 4);
@@ -101,13 +90,13 @@ __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const vo
         }
 }
 
-template <int EMAX, int R, bool WG_BF16>
+template <int EMAX, int R, bool WG16, int DT>
 __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16_t *__restrict__ x, const void *__restrict__ wg,
                                                           float *__restrict__ logits, int S, int M, int E) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + wave) * R;
     if (row0 >= S) return;
-    gate_rows<EMAX, R, WG_BF16>(x, wg, logits, S, M, E, row0, lane);
+    gate_rows<EMAX, R, WG16, DT>(x, wg, logits, S, M, E, row0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -474,14 +463,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void route_fused_kernel(
 // (same arithmetic as gate_logits_kernel, so the logits are bit-identical), the logits go to global memory (they are an
 // output), and after the barrier the block routes them.
 constexpr int GATE_ROUTE_MAX_S = 64;
-template <int EMAX, bool WG_BF16>
+template <int EMAX, bool WG16, int DT>
 __global__ __launch_bounds__(FUSED_THREADS) void gate_route_fused_kernel(
     const bf16_t *__restrict__ x, const void *__restrict__ wg, int M, float *logits, const float *__restrict__ noise,
     unsigned long long seed, unsigned long long *seed_dev, int S, int E, int capacity, int drop_tokens,
     int *__restrict__ expert_idx, int *__restrict__ slot, float *__restrict__ weight, long long *__restrict__ exp_counts,
     int *__restrict__ kept_counts, int *__restrict__ expert_offsets, int *__restrict__ perm, float *__restrict__ l_aux) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave * 4 < S) gate_rows<EMAX, 4, WG_BF16>(x, wg, logits, S, M, E, wave * 4, lane);
+    if (wave * 4 < S) gate_rows<EMAX, 4, WG16, DT>(x, wg, logits, S, M, E, wave * 4, lane);
     __threadfence_block();
     __syncthreads();  // the block's own global writes are visible to it after the barrier
     route_fused_body<EMAX>(logits, noise, seed, seed_dev, S, E, capacity, drop_tokens, expert_idx, slot, weight, exp_counts,
@@ -505,7 +494,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t *__restri
     }
 }
 
-template <int TOPK>
+template <int TOPK, int DT>
 __global__ __launch_bounds__(256) void combine_kernel(const bf16_t *__restrict__ y, const int *__restrict__ expert_idx,
                                                       const int *__restrict__ slot, const float *__restrict__ weight,
                                                       const int *__restrict__ expert_offsets, int S, int M,
@@ -517,7 +506,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const bf16_t *__restrict__
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) {
             const int sl = slot[s * TOPK + j];
-            const float wq = rbf(weight[s * TOPK + j]);  // combine_weights.type_as(x)
+            const float wq = Elt<DT>::round(weight[s * TOPK + j]);  // combine_weights.type_as(x)
             const bool on = sl >= 0 && wq != 0.f;
             w[j] = on ? wq : 0.f;
             const size_t pos = on ? (size_t)(expert_offsets[expert_idx[s * TOPK + j]] + sl) : 0;
@@ -531,22 +520,14 @@ __global__ __launch_bounds__(256) void combine_kernel(const bf16_t *__restrict__
 #pragma unroll
             for (int j = 0; j < TOPK; ++j) {
                 if (src[j] != nullptr) {
-                    const uint4 v = src[j][c];
-                    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+                    float yv[8];
+                    unpack8_t<DT>(src[j][c], yv);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        // bf16*bf16 products are exact in fp32, so the two-term sum rounds once
-                        acc[2 * i] += w[j] * __builtin_bit_cast(float, u[i] << 16);
-                        acc[2 * i + 1] += w[j] * __builtin_bit_cast(float, u[i] & 0xffff0000u);
-                    }
+                    for (int i = 0; i < 8; ++i) acc[i] += w[j] * yv[i];  // 16-bit x 16-bit products are exact in fp32:
+                                                                         // the two-term sum rounds once
                 }
             }
-            uint4 o;
-            o.x = (unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16);
-            o.y = (unsigned)f2bf(acc[2]) | ((unsigned)f2bf(acc[3]) << 16);
-            o.z = (unsigned)f2bf(acc[4]) | ((unsigned)f2bf(acc[5]) << 16);
-            o.w = (unsigned)f2bf(acc[6]) | ((unsigned)f2bf(acc[7]) << 16);
-            dp[c] = o;
+            dp[c] = pack8_t<DT>(acc);
         }
     }
 }
@@ -580,23 +561,38 @@ using namespace moe;
 extern "C" int moe_abi_version(void) { return MOE_ABI_VERSION; }
 extern "C" const char *moe_last_error(void) { return err_buf(); }
 
-extern "C" int moe_gate_logits_fwd(const void *x, const void *wg, int wg_is_bf16, float *logits, int S, int M, int E,
-                                   void *stream) {
+// wg_dtype / dtype of a gate call -> (ok, wg is 16-bit)
+static int gate_types_ok(const char *fn, int wg_dtype, int dtype, bool *wg16) {
+    if (dtype != MOE_DTYPE_BF16 && dtype != MOE_DTYPE_F16) return fail(MOE_ERR_ARG, "%s: unknown dtype %d", fn, dtype);
+    if (wg_dtype != MOE_WG_F32 && wg_dtype != (dtype == MOE_DTYPE_BF16 ? MOE_WG_BF16 : MOE_WG_F16))
+        return fail(MOE_ERR_ARG, "%s: wg must be fp32 or of the activations' 16-bit type (wg_dtype=%d, dtype=%d)", fn, wg_dtype,
+                    dtype);
+    *wg16 = wg_dtype != MOE_WG_F32;
+    return 0;
+}
+
+extern "C" int moe_gate_logits_fwd(const void *x, const void *wg, int wg_dtype, float *logits, int S, int M, int E,
+                                   int dtype, void *stream) {
     if (!x || !wg || !logits) return fail(MOE_ERR_ARG, "moe_gate_logits_fwd: null pointer");
+    bool wg16 = false;
+    if (int rc = gate_types_ok("moe_gate_logits_fwd", wg_dtype, dtype, &wg16)) return rc;
     if (S < 0 || M <= 0 || (M & 7) || E < 1 || E > 64)
         return fail(MOE_ERR_SHAPE, "moe_gate_logits_fwd: need S>=0, M%%8==0, 1<=E<=64 (S=%d M=%d E=%d)", S, M, E);
     if (!aligned16(x) || !aligned16(wg)) return fail(MOE_ERR_ALIGN, "moe_gate_logits_fwd: x / wg not 16-byte aligned");
     if (S == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *xp = (const bf16_t *)x;
+#define LAUNCH_GATE_T(EM, RR, W16, DT_)                                                                          \
+    hipLaunchKernelGGL((gate_logits_kernel<EM, RR, W16, DT_>), grid, dim3(256), 0, st, xp, wg, logits, S, M, E)
 #define LAUNCH_GATE(EM, RR)                                                                                      \
     do {                                                                                                         \
         const int rows_per_block = 4 * RR;                                                                       \
         dim3 grid((S + rows_per_block - 1) / rows_per_block);                                                    \
-        if (wg_is_bf16)                                                                                          \
-            hipLaunchKernelGGL((gate_logits_kernel<EM, RR, true>), grid, dim3(256), 0, st, xp, wg, logits, S, M, E); \
-        else                                                                                                     \
-            hipLaunchKernelGGL((gate_logits_kernel<EM, RR, false>), grid, dim3(256), 0, st, xp, wg, logits, S, M, E); \
+        if (dtype == MOE_DTYPE_BF16) {                                                                           \
+            if (wg16) LAUNCH_GATE_T(EM, RR, true, DT_BF16); else LAUNCH_GATE_T(EM, RR, false, DT_BF16);          \
+        } else {                                                                                                 \
+            if (wg16) LAUNCH_GATE_T(EM, RR, true, DT_F16); else LAUNCH_GATE_T(EM, RR, false, DT_F16);            \
+        }                                                                                                        \
     } while (0)
     // small S: 2 rows per wave so that the grid covers more CUs (24 vs 28 us gate + routing at S = 704); large S: 4
     // rows per wave (8 measured no better)
@@ -606,6 +602,7 @@ extern "C" int moe_gate_logits_fwd(const void *x, const void *wg, int wg_is_bf16
     else if (E <= 16) LAUNCH_GATE(16, 2);
     else LAUNCH_GATE(64, 1);
 #undef LAUNCH_GATE
+#undef LAUNCH_GATE_T
     return check_launch("gate_logits_kernel");
 }
 
@@ -669,13 +666,15 @@ static int routing_top2_launch(const float *logits, const float *noise, uint64_t
 namespace moe {
 // gate + routing of a decode step in one launch (internal: moe_block_top2_fwd* use it when it applies)
 bool gate_route_small_applies(int S, int E) { return S >= 1 && S <= GATE_ROUTE_MAX_S && E >= 2 && E <= 8; }
-int launch_gate_route_small(const void *x, const void *wg, int wg_is_bf16, float *logits, const float *noise,
+int launch_gate_route_small(const void *x, int dtype, const void *wg, int wg_dtype, float *logits, const float *noise,
                             uint64_t noise_seed, uint64_t *noise_seed_dev, int S, int M, int E, int capacity,
                             int drop_tokens, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                             int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux, void *stream) {
     if (!x || !wg || !logits || !expert_idx || !slot || !weight || !exp_counts || !kept_counts || !expert_offsets || !perm ||
         !l_aux)
         return fail(MOE_ERR_ARG, "moe_block_top2_fwd: null pointer");
+    bool wg16 = false;
+    if (int rc = gate_types_ok("moe_block_top2_fwd", wg_dtype, dtype, &wg16)) return rc;
     if (!gate_route_small_applies(S, E) || M <= 0 || (M & 7))
         return fail(MOE_ERR_SHAPE, "moe_block_top2_fwd: need M%%8==0 (S=%d M=%d E=%d)", S, M, E);
     if (drop_tokens && capacity < 0) return fail(MOE_ERR_SHAPE, "moe_block_top2_fwd: negative capacity");
@@ -685,13 +684,22 @@ int launch_gate_route_small(const void *x, const void *wg, int wg_is_bf16, float
         ((uintptr_t)noise_seed_dev & 7))
         return fail(MOE_ERR_ALIGN, "moe_block_top2_fwd: x / wg need 16-byte, [S,2] arrays and the seed 8-byte alignment");
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_GR(EM, BF)                                                                                                 \
-    hipLaunchKernelGGL((gate_route_fused_kernel<EM, BF>), dim3(1), dim3(FUSED_THREADS), 0, st, (const bf16_t *)x, wg, M,     \
-                       logits, noise, (unsigned long long)noise_seed, (unsigned long long *)noise_seed_dev, S, E, capacity,  \
-                       drop_tokens, expert_idx, slot, weight, (long long *)exp_counts, kept_counts, expert_offsets, perm,    \
-                       l_aux)
-    if (E <= 4) { if (wg_is_bf16) LAUNCH_GR(4, true); else LAUNCH_GR(4, false); }
-    else { if (wg_is_bf16) LAUNCH_GR(8, true); else LAUNCH_GR(8, false); }
+#define LAUNCH_GR(EM, W16, DT_)                                                                                           \
+    hipLaunchKernelGGL((gate_route_fused_kernel<EM, W16, DT_>), dim3(1), dim3(FUSED_THREADS), 0, st, (const bf16_t *)x, wg,  \
+                       M, logits, noise, (unsigned long long)noise_seed, (unsigned long long *)noise_seed_dev, S, E,         \
+                       capacity, drop_tokens, expert_idx, slot, weight, (long long *)exp_counts, kept_counts,                \
+                       expert_offsets, perm, l_aux)
+#define LAUNCH_GR_E(EM)                                                                                  \
+    do {                                                                                                 \
+        if (dtype == MOE_DTYPE_BF16) {                                                                   \
+            if (wg16) LAUNCH_GR(EM, true, DT_BF16); else LAUNCH_GR(EM, false, DT_BF16);                  \
+        } else {                                                                                         \
+            if (wg16) LAUNCH_GR(EM, true, DT_F16); else LAUNCH_GR(EM, false, DT_F16);                    \
+        }                                                                                                \
+    } while (0)
+    if (E <= 4) LAUNCH_GR_E(4);
+    else LAUNCH_GR_E(8);
+#undef LAUNCH_GR_E
 #undef LAUNCH_GR
     return check_launch("gate_route_fused_kernel");
 }
@@ -784,20 +792,21 @@ extern "C" int moe_gather_rows_fwd(const void *src, const int32_t *gather, int g
 }
 
 extern "C" int moe_combine_fwd(const void *y, const int32_t *expert_idx, const int32_t *slot, const float *weight,
-                               const int32_t *expert_offsets, int S, int M, int top_k, void *out, void *stream) {
+                               const int32_t *expert_offsets, int S, int M, int top_k, void *out, int dtype, void *stream) {
     if (!y || !expert_idx || !slot || !weight || !expert_offsets || !out)
         return fail(MOE_ERR_ARG, "moe_combine_fwd: null pointer");
+    if (dtype != MOE_DTYPE_BF16 && dtype != MOE_DTYPE_F16) return fail(MOE_ERR_ARG, "moe_combine_fwd: unknown dtype %d", dtype);
     if (S < 0 || M <= 0 || (M & 7) || (top_k != 1 && top_k != 2))
         return fail(MOE_ERR_SHAPE, "moe_combine_fwd: need M%%8==0 and top_k in {1,2}");
     if (!aligned16(y) || !aligned16(out)) return fail(MOE_ERR_ALIGN, "moe_combine_fwd: y / out not 16-byte aligned");
     if (S == 0) return 0;
     const int grid = S < 16384 ? S : 16384;
     hipStream_t st = (hipStream_t)stream;
-    if (top_k == 2)
-        hipLaunchKernelGGL((combine_kernel<2>), dim3(grid), dim3(256), 0, st, (const bf16_t *)y, expert_idx, slot, weight,
-                           expert_offsets, S, M, (bf16_t *)out);
-    else
-        hipLaunchKernelGGL((combine_kernel<1>), dim3(grid), dim3(256), 0, st, (const bf16_t *)y, expert_idx, slot, weight,
-                           expert_offsets, S, M, (bf16_t *)out);
+#define LAUNCH_COMBINE(K_, DT_)                                                                                          \
+    hipLaunchKernelGGL((combine_kernel<K_, DT_>), dim3(grid), dim3(256), 0, st, (const bf16_t *)y, expert_idx, slot, weight, \
+                       expert_offsets, S, M, (bf16_t *)out)
+    if (dtype == MOE_DTYPE_BF16) { if (top_k == 2) LAUNCH_COMBINE(2, DT_BF16); else LAUNCH_COMBINE(1, DT_BF16); }
+    else { if (top_k == 2) LAUNCH_COMBINE(2, DT_F16); else LAUNCH_COMBINE(1, DT_F16); }
+#undef LAUNCH_COMBINE
     return check_launch("combine_kernel");
 }

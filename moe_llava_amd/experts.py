@@ -165,9 +165,11 @@ class Experts(nn.Module):
             if self._external:
                 self._copy_in(specs, pk)
             return specs[0].act, pk["w1"], pk["b1"], pk["w2"], pk["b2"]
+        dtype = params[0].dtype
         for p in params:
-            if p.dtype != torch.bfloat16:
-                raise TypeError(f"expert parameters must be bf16 (got {p.dtype}); cast the model with .to(torch.bfloat16)")
+            if p.dtype not in ops.HALF_DTYPES or p.dtype != dtype:
+                raise TypeError(f"expert parameters must all be bf16 or all fp16 (got {p.dtype}); cast the model with "
+                                ".to(torch.bfloat16) / .to(torch.float16)")
             if p.device != device:
                 raise ValueError(f"expert parameter on {p.device}, activations on {device}")
         E = len(specs)
@@ -189,7 +191,7 @@ class Experts(nn.Module):
             raise NotImplementedError("RePaMLP mask is not a prefix mask; only prefix masks are implemented")
         has_b1 = specs[0].fc1[0].bias is not None
         has_b2 = specs[0].fc2.bias is not None
-        kw = dict(dtype=torch.bfloat16, device=device)
+        kw = dict(dtype=dtype, device=device)
         for s in specs:
             if any((lin.bias is not None) != has_b1 for lin in s.fc1):
                 raise ValueError("bias must be present on all fc1 projections or none")

@@ -19,6 +19,8 @@ from typing import Optional
 import torch
 from torch import Tensor
 
+from . import ops
+
 
 class GraphedMoE:
     """``g = GraphedMoE(moe, example)`` then ``out, l_aux, exp_counts = g(x)`` with ``x.shape == example.shape``.
@@ -30,8 +32,8 @@ class GraphedMoE:
     def __init__(self, moe, example: Tensor, seed: Optional[int] = None, warmup: int = 2):
         layer = getattr(moe, "deepspeed_moe", moe)
         gate = layer.gate
-        if not example.is_cuda or example.dtype != torch.bfloat16:
-            raise TypeError("GraphedMoE: example must be a bf16 tensor on the GPU")
+        if not example.is_cuda or example.dtype not in ops.HALF_DTYPES:
+            raise TypeError("GraphedMoE: example must be a bf16 or fp16 tensor on the GPU")
         if layer.ep_size != 1 or layer.force_exchange:
             raise NotImplementedError("GraphedMoE: expert-parallel steps are not captured (the exchange sizes its "
                                       "splits on the host)")

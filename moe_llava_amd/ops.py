@@ -15,6 +15,29 @@ from . import _lib
 ACT_SWIGLU = 0
 ACT_GELU_NEW = 1
 EPI_PLAIN, EPI_SWIGLU, EPI_GELU_NEW = 0, 1, 2
+DTYPE_BF16, DTYPE_F16 = 0, 1                 # MOE_DTYPE_* of the C ABI
+WG_F32, WG_BF16, WG_F16 = 0, 1, 2            # MOE_WG_*
+#: element types of the forward path: bf16 (training, --bf16 serving) and fp16 (the reference's inference loader,
+#: moellava/model/builder.py:70,475).  The backward entry points are bf16 only.
+HALF_DTYPES = (torch.bfloat16, torch.float16)
+
+
+def _dt(t: Tensor) -> int:
+    """MOE_DTYPE_* of a 16-bit activation / weight tensor."""
+    if t.dtype == torch.bfloat16:
+        return DTYPE_BF16
+    if t.dtype == torch.float16:
+        return DTYPE_F16
+    raise TypeError(f"expected bf16 or fp16, got {t.dtype}")
+
+
+def _wg_dt(wg: Tensor, x: Tensor) -> int:
+    """MOE_WG_* of the gate weight: fp32, or the activations' own 16-bit type (what ``model.to(dtype)`` leaves)."""
+    if wg.dtype == torch.float32:
+        return WG_F32
+    if wg.dtype == x.dtype and wg.dtype in HALF_DTYPES:
+        return WG_BF16 if wg.dtype == torch.bfloat16 else WG_F16
+    raise TypeError(f"wg.weight: expected fp32 or the activations' dtype ({x.dtype}), got {wg.dtype}")
 
 
 class PhaseTimer:
@@ -102,7 +125,7 @@ def _need(t: Tensor, name: str, dtype, ndim: Optional[int] = None) -> None:
         raise TypeError(f"{name}: expected a tensor")
     if not t.is_cuda:
         raise _lib.MoEKernelError(f"{name}: must live on the GPU (got {t.device}); there is no CPU path")
-    if t.dtype != dtype:
+    if (t.dtype not in dtype) if isinstance(dtype, tuple) else (t.dtype != dtype):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if ndim is not None and t.dim() != ndim:
         raise ValueError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
@@ -189,9 +212,8 @@ class Routing:
 
 def gate_logits(x: Tensor, wg_weight: Tensor) -> Tensor:
     """logits = x.float() @ wg.float().T  ([S,E] fp32) -- TopKGate.forward's F.linear."""
-    _need(x, "x", torch.bfloat16, 2)
-    if wg_weight.dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError(f"wg.weight: expected fp32 or bf16, got {wg_weight.dtype}")
+    _need(x, "x", HALF_DTYPES, 2)
+    wgd = _wg_dt(wg_weight, x)
     _need(wg_weight, "wg.weight", wg_weight.dtype, 2)
     S, M = x.shape
     E = wg_weight.shape[0]
@@ -200,8 +222,8 @@ def gate_logits(x: Tensor, wg_weight: Tensor) -> Tensor:
     logits = torch.empty((S, E), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     with _on(x.device):
-        rc = lib.moe_gate_logits_fwd(x.data_ptr(), wg_weight.data_ptr(), int(wg_weight.dtype == torch.bfloat16),
-                                     logits.data_ptr(), S, M, E, _stream_ptr(x))
+        rc = lib.moe_gate_logits_fwd(x.data_ptr(), wg_weight.data_ptr(), wgd, logits.data_ptr(), S, M, E, _dt(x),
+                                     _stream_ptr(x))
     _lib.check(rc, "moe_gate_logits_fwd")
     return logits
 
@@ -269,9 +291,9 @@ def routing_top1(logits: Tensor, capacity: int, used_token: Optional[Tensor] = N
 
 
 def _check_ffn_weights(act, a, w1, b1, w2, b2):
-    _need(a, "a", torch.bfloat16, 2)
-    _need(w1, "w1", torch.bfloat16, 3)
-    _need(w2, "w2", torch.bfloat16, 3)
+    _need(a, "a", HALF_DTYPES, 2)
+    _need(w1, "w1", a.dtype, 3)            # activations and expert weights share one 16-bit type
+    _need(w2, "w2", a.dtype, 3)
     M = a.shape[1]
     n_local, M2, I = w2.shape
     n1 = 2 * I if act == ACT_SWIGLU else I
@@ -279,7 +301,7 @@ def _check_ffn_weights(act, a, w1, b1, w2, b2):
         raise ValueError(f"weight shapes w1 {tuple(w1.shape)} / w2 {tuple(w2.shape)} do not match M={M}, act={act}")
     for b, name, n in ((b1, "b1", n1), (b2, "b2", M)):
         if b is not None:
-            _need(b, name, torch.bfloat16, 2)
+            _need(b, name, a.dtype, 2)
             if tuple(b.shape) != (n_local, n):
                 raise ValueError(f"{name}: expected {(n_local, n)}, got {tuple(b.shape)}")
             if b.device != a.device:
@@ -292,10 +314,11 @@ def _check_ffn_weights(act, a, w1, b1, w2, b2):
 def _expert_ffn_launch(act, a, gather_ptr, gather_shift, w1, b1, w2, b2, offs_ptr, G, max_rows, M, I, n_local, timer,
                        n_gated):
     dev = a.device
-    y = torch.empty((max(max_rows, 1), M), dtype=torch.bfloat16, device=dev)
+    y = torch.empty((max(max_rows, 1), M), dtype=a.dtype, device=dev)
     if max_rows == 0:
         return y
-    h = torch.empty((max_rows, I), dtype=torch.bfloat16, device=dev)
+    h = torch.empty((max_rows, I), dtype=a.dtype, device=dev)
+    dt = _dt(a)
     lib = _lib.load()
     b1p = b1.data_ptr() if b1 is not None else None
     b2p = b2.data_ptr() if b2 is not None else None
@@ -304,18 +327,18 @@ def _expert_ffn_launch(act, a, gather_ptr, gather_shift, w1, b1, w2, b2, offs_pt
         if timer is None:
             rc = lib.moe_expert_ffn_fwd(act, a.data_ptr(), a.stride(0), gather_ptr, gather_shift, w1.data_ptr(), b1p,
                                         w2.data_ptr(), b2p, offs_ptr, G, n_local, max_rows, M, I, n_gated, h.data_ptr(),
-                                        y.data_ptr(), st)
+                                        y.data_ptr(), dt, st)
             _lib.check(rc, "moe_expert_ffn_fwd")
         else:
             # same two launches through the single-GEMM primitive, with events between them
             epi = EPI_SWIGLU if act == ACT_SWIGLU else EPI_GELU_NEW
             timer.mark("fc1_begin")
             rc = lib.moe_grouped_gemm_fwd(epi, a.data_ptr(), a.stride(0), gather_ptr, gather_shift, w1.data_ptr(), b1p,
-                                          offs_ptr, G, n_local, max_rows, M, I, n_gated, h.data_ptr(), I, st)
+                                          offs_ptr, G, n_local, max_rows, M, I, n_gated, h.data_ptr(), I, dt, st)
             _lib.check(rc, "moe_grouped_gemm_fwd(fc1)")
             timer.mark("fc1_end")
             rc = lib.moe_grouped_gemm_fwd(EPI_PLAIN, h.data_ptr(), I, None, 0, w2.data_ptr(), b2p, offs_ptr, G, n_local,
-                                          max_rows, I, M, -1, y.data_ptr(), M, st)
+                                          max_rows, I, M, -1, y.data_ptr(), M, dt, st)
             _lib.check(rc, "moe_grouped_gemm_fwd(fc2)")
             timer.mark("fc2_end")
     return y
@@ -363,8 +386,8 @@ def block_top2(x: Tensor, wg_weight: Tensor, capacity: int, noise: Optional[Tens
     Returns (out [S,M] bf16, logits [S,E] fp32, Routing).  ``noise_seed_dev`` (1-element int64 device tensor): the
     Gumbel seed lives on the device and the routing kernel advances it -- the form a HIP graph can replay."""
     M, I, n_local = _check_ffn_weights(act, x, w1, b1, w2, b2)
-    if wg_weight.dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError(f"wg.weight: expected fp32 or bf16, got {wg_weight.dtype}")
+    wgd = _wg_dt(wg_weight, x)
+    dt = _dt(x)
     _need(wg_weight, "wg.weight", wg_weight.dtype, 2)
     S = x.shape[0]
     E = wg_weight.shape[0]
@@ -381,8 +404,8 @@ def block_top2(x: Tensor, wg_weight: Tensor, capacity: int, noise: Optional[Tens
     r = Routing.allocate(S, E, 2, max_rows, int(capacity), ws_bytes, dev)
     logits = torch.empty((S, E), dtype=torch.float32, device=dev)
     rows = max(max_rows, 1)
-    hy = torch.empty((rows * (I + M),), dtype=torch.bfloat16, device=dev)   # h workspace, then y
-    out = torch.empty((S, M), dtype=torch.bfloat16, device=dev)
+    hy = torch.empty((rows * (I + M),), dtype=x.dtype, device=dev)   # h workspace, then y
+    out = torch.empty((S, M), dtype=x.dtype, device=dev)
     hp = hy.data_ptr()
     if noise_seed_dev is not None:
         _need(noise_seed_dev, "noise_seed_dev", torch.int64)
@@ -390,23 +413,23 @@ def block_top2(x: Tensor, wg_weight: Tensor, capacity: int, noise: Optional[Tens
             raise ValueError("noise_seed_dev: one int64 on x's device, and no noise tensor with it")
         with _on(dev):
             rc = lib.moe_block_top2_fwd_dseed(
-                x.data_ptr(), wg_weight.data_ptr(), int(wg_weight.dtype == torch.bfloat16), logits.data_ptr(),
+                x.data_ptr(), wg_weight.data_ptr(), wgd, logits.data_ptr(),
                 noise_seed_dev.data_ptr(), S, M, E, I, act,
                 int(capacity), int(bool(drop_tokens)), n_gated, r.ptr("expert_idx"), r.ptr("slot"), r.ptr("weight"),
                 r.ptr("exp_counts"), r.ptr("kept_counts"), r.ptr("expert_offsets"), r.ptr("perm"), r.ptr("l_aux"),
                 r.ptr("workspace"), ws_bytes, w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
-                b2.data_ptr() if b2 is not None else None, hp, hp + rows * I * 2, out.data_ptr(), _stream_ptr(x))
+                b2.data_ptr() if b2 is not None else None, hp, hp + rows * I * 2, out.data_ptr(), dt, _stream_ptr(x))
         _lib.check(rc, "moe_block_top2_fwd_dseed")
         r._keep = hy
         return out, logits, r
     with _on(dev):
         rc = lib.moe_block_top2_fwd(
-            x.data_ptr(), wg_weight.data_ptr(), int(wg_weight.dtype == torch.bfloat16), logits.data_ptr(),
+            x.data_ptr(), wg_weight.data_ptr(), wgd, logits.data_ptr(),
             noise.data_ptr() if noise is not None else None, int(noise_seed) & 0xFFFFFFFFFFFFFFFF, S, M, E, I, act,
             int(capacity), int(bool(drop_tokens)), n_gated, r.ptr("expert_idx"), r.ptr("slot"), r.ptr("weight"),
             r.ptr("exp_counts"), r.ptr("kept_counts"), r.ptr("expert_offsets"), r.ptr("perm"), r.ptr("l_aux"),
             r.ptr("workspace"), ws_bytes, w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
-            b2.data_ptr() if b2 is not None else None, hp, hp + rows * I * 2, out.data_ptr(), _stream_ptr(x))
+            b2.data_ptr() if b2 is not None else None, hp, hp + rows * I * 2, out.data_ptr(), dt, _stream_ptr(x))
     _lib.check(rc, "moe_block_top2_fwd")
     r._keep = hy                                   # y lives in hy; keep it alive with the routing (inspection only)
     return out, logits, r
@@ -414,12 +437,12 @@ def block_top2(x: Tensor, wg_weight: Tensor, capacity: int, noise: Optional[Tens
 
 def gather_rows(src: Tensor, gather: Tensor, gather_shift: int, n_rows_dev: Tensor, max_rows: int) -> Tensor:
     """dst[p] = src[gather[p] >> shift] for p < n_rows_dev[0] (expert-sorted send buffer of the EP all-to-all)."""
-    _need(src, "src", torch.bfloat16, 2)
+    _need(src, "src", HALF_DTYPES, 2)
     _need(gather, "gather", torch.int32, 1)
     _need(n_rows_dev, "n_rows_dev", torch.int32)
     if gather.numel() < max_rows:
         raise ValueError("gather shorter than max_rows")
-    dst = torch.empty((max(max_rows, 1), src.shape[1]), dtype=torch.bfloat16, device=src.device)
+    dst = torch.empty((max(max_rows, 1), src.shape[1]), dtype=src.dtype, device=src.device)
     lib = _lib.load()
     with _on(src.device):
         rc = lib.moe_gather_rows_fwd(src.data_ptr(), gather.data_ptr(), gather_shift, n_rows_dev.data_ptr(),
@@ -430,16 +453,16 @@ def gather_rows(src: Tensor, gather: Tensor, gather_shift: int, n_rows_dev: Tens
 
 def combine(y: Tensor, r: Routing, S: int, M: int) -> Tensor:
     """out[s] = sum_j bf16(w[s,j]) * y[pos(s,j)]  (the ``sec,ecm->sm`` einsum)."""
-    _need(y, "y", torch.bfloat16, 2)
+    _need(y, "y", HALF_DTYPES, 2)
     if y.shape[1] != M or y.shape[0] < r.max_rows:
         raise ValueError(f"y {tuple(y.shape)} too small for max_rows={r.max_rows}, M={M}")
     if r.S != S:
         raise ValueError("routing does not match S")
-    out = torch.empty((S, M), dtype=torch.bfloat16, device=y.device)
+    out = torch.empty((S, M), dtype=y.dtype, device=y.device)
     lib = _lib.load()
     with _on(y.device):
         rc = lib.moe_combine_fwd(y.data_ptr(), r.ptr("expert_idx"), r.ptr("slot"), r.ptr("weight"),
-                                 r.ptr("expert_offsets"), S, M, r.top_k, out.data_ptr(), _stream_ptr(y))
+                                 r.ptr("expert_offsets"), S, M, r.top_k, out.data_ptr(), _dt(y), _stream_ptr(y))
     _lib.check(rc, "moe_combine_fwd")
     return out
 

@@ -210,12 +210,17 @@ class MOELayer(nn.Module):
     def forward(self, *inp) -> Tensor:
         x_in = inp[0]
         used_token = inp[1] if len(inp) > 1 else None
-        if x_in.dtype != torch.bfloat16:
-            raise TypeError(f"MoE block runs in bf16 (the reference trains and serves with --bf16); got {x_in.dtype}")
+        if x_in.dtype not in ops.HALF_DTYPES:
+            # the reference trains and serves with --bf16 (scripts/v1/*/finetune_moe.sh) and builds the model in fp16 in
+            # its inference loader (moellava/model/builder.py:70,475; serve/cli.py:67-69): both run, nothing else does
+            raise TypeError(f"MoE block runs in bf16 or fp16; got {x_in.dtype}")
         wg = self.gate.wg.weight
         if torch.is_grad_enabled():
             params = self.experts.param_list()
             if x_in.requires_grad or wg.requires_grad or any(p.requires_grad for p in params):
+                if x_in.dtype != torch.bfloat16:
+                    raise NotImplementedError("training runs in bf16 (as the reference's scripts do, --bf16 True); the fp16 "
+                                              "path is forward only: wrap inference in torch.no_grad()")
                 # training: one autograd node for the whole block; l_aux stays differentiable
                 # because the reference adds it to the loss (llava_stablelm_moe.py:461-472)
                 out, self.l_aux = _MoEBlockFn.apply(self, used_token, x_in, wg, *params)
@@ -335,7 +340,7 @@ class MOELayer(nn.Module):
         if not save and chunks > 1:
             return self._expert_parallel_chunked(x, r, act, w1, b1, w2, b2, kept_h, me, chunks), None
         send = ops.gather_rows(x, r.perm, r.top_k - 1, r.expert_offsets[E:E + 1], n_send)
-        recv = torch.empty((max(n_recv, 1), M), dtype=torch.bfloat16, device=x.device)
+        recv = torch.empty((max(n_recv, 1), M), dtype=x.dtype, device=x.device)
         _all_to_all_rows(recv[:n_recv], send[:n_send], recv_splits, send_splits, self.ep_group)
         # received rows are ordered (src, local expert): ep*El groups, group g uses expert g % El
         offs_h = torch.zeros(ep * El + 1, dtype=torch.int32)
@@ -349,7 +354,7 @@ class MOELayer(nn.Module):
         else:
             y_recv = ops.expert_ffn(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv, timer=self.timer,
                                     n_gated=self.experts.n_gated)
-        y = torch.empty((max(n_send, r.max_rows, 1), M), dtype=torch.bfloat16, device=x.device)
+        y = torch.empty((max(n_send, r.max_rows, 1), M), dtype=x.dtype, device=x.device)
         _all_to_all_rows(y[:n_send], y_recv[:n_recv], send_splits, recv_splits, self.ep_group)
         return y, saved
 
@@ -399,12 +404,12 @@ def _expert_parallel_chunked(self, x, r, act, w1, b1, w2, b2, kept_h, me, C):
     recvs, works = [], []
     for c in range(C):
         n_rc = int(offs_h[c, -1])
-        rc = torch.empty((max(n_rc, 1), M), dtype=torch.bfloat16, device=dev)
+        rc = torch.empty((max(n_rc, 1), M), dtype=x.dtype, device=dev)
         w = _all_to_all_rows_async(rc[:n_rc], send[send_edges[c]:send_edges[c + 1]], recv_cnt[:, :, c].sum(1).tolist(),
                                    send_cnt[:, c].tolist(), self.ep_group)
         recvs.append((rc, n_rc))
         works.append(w)
-    y_cm = torch.empty((max(n_send, 1), M), dtype=torch.bfloat16, device=dev)   # returned rows, chunk-major
+    y_cm = torch.empty((max(n_send, 1), M), dtype=x.dtype, device=dev)   # returned rows, chunk-major
     back, keep = [], []
     # The chunks' grouped FFNs alternate between the compute stream and a side stream: a chunk launch is only a few
     # rounds of 256-row tiles (fc2: 1.4 rounds at the bench's shapes), and with two streams the next chunk's blocks

@@ -14,7 +14,10 @@ Files written:
   top1_S512_E4.npz         top-1 with RTS uniforms, used_token, RSample noise
   block_stablelm.npz       whole block, StableLM experts (M 128, I 320, E 4, S 333): x, weights, fp32 logits, outputs
   block_phi.npz            whole block, Phi experts with biases (M 128, I 256, E 4, S 260)
-bf16 tensors are stored as their uint16 bit patterns."""
+  block_stablelm_fp16.npz  the StableLM block in fp16 (the reference's inference dtype, moellava/model/builder.py:70), gate
+                           weight in fp16 too as after model.to(torch.float16); written by `make_golden.py --fp16-only`
+                           (round 2) so that the round-1 files keep their bytes
+bf16 / fp16 tensors are stored as their uint16 bit patterns."""
 import json
 import os
 import sys
@@ -85,15 +88,17 @@ def top1_case():
     return out
 
 
-def block_case(kind, M, I, E, B, T, cf, seed):
+def block_case(kind, M, I, E, B, T, cf, seed, dtype=torch.bfloat16):
     g = torch.Generator().manual_seed(seed)
-    proto = (StableLMMLPRef(M, I) if kind == "stablelm" else PhiMLPRef(M, I)).to(torch.bfloat16)
+    proto = (StableLMMLPRef(M, I) if kind == "stablelm" else PhiMLPRef(M, I)).to(dtype)
     moe = lit.MoERef(M, proto, num_experts=E, k=2, capacity_factor=cf, eval_capacity_factor=2.0, min_capacity=0,
                      top2_2nd_expert_sampling=False)
     for p in moe.deepspeed_moe.experts.parameters():
-        p.data = (torch.randn(p.shape, generator=g) * 0.05).to(torch.bfloat16)
+        p.data = (torch.randn(p.shape, generator=g) * 0.05).to(dtype)
     moe.deepspeed_moe.gate.wg.weight.data = torch.randn(E, M, generator=g) * 0.1
-    x = torch.randn(B, T, M, generator=g).to(torch.bfloat16)
+    if dtype == torch.float16:   # model.to(torch.float16) casts the gate too (builder.py:475); values stay fp16-exact
+        moe.deepspeed_moe.gate.wg.weight.data = moe.deepspeed_moe.gate.wg.weight.data.to(dtype).float()
+    x = torch.randn(B, T, M, generator=g).to(dtype)
     moe.train()
     with torch.no_grad():
         out, l_aux, counts = moe(x)
@@ -106,6 +111,11 @@ def block_case(kind, M, I, E, B, T, cf, seed):
 
 
 def main():
+    if "--fp16-only" in sys.argv:
+        np.savez_compressed(os.path.join(OUT, "block_stablelm_fp16.npz"),
+                            **block_case("stablelm", 128, 320, 4, 3, 111, 1.5, 23, torch.float16))
+        print("block_stablelm_fp16.npz", os.path.getsize(os.path.join(OUT, "block_stablelm_fp16.npz")))
+        return
     # hand-derived case of SURVEY 8a'' (l_aux there is printed as 1.493633; exact fp32 arithmetic gives 1.4936405)
     logits = torch.tensor([[3., 2., 1.], [3., 1., 2.], [2., 3., 1.], [3., 2., 1.]])
     l_aux, combine, dispatch, counts = lit.top2gating_dense(logits.clone(), 0.75, 0, True, None)
@@ -126,6 +136,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "top1_S512_E4.npz"), **top1_case())
     np.savez_compressed(os.path.join(OUT, "block_stablelm.npz"), **block_case("stablelm", 128, 320, 4, 3, 111, 1.5, 21))
     np.savez_compressed(os.path.join(OUT, "block_phi.npz"), **block_case("phi", 128, 256, 4, 2, 130, 1.0, 22))
+    np.savez_compressed(os.path.join(OUT, "block_stablelm_fp16.npz"),
+                        **block_case("stablelm", 128, 320, 4, 3, 111, 1.5, 23, torch.float16))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -118,23 +118,23 @@ def test_gate_logits_numerics(S, M, E, wg_dtype):
     assert torch.allclose(got, ref32, atol=tol, rtol=0)
 
 
-def _mk_experts(kind, M, I, E, seed, scale=0.05):
+def _mk_experts(kind, M, I, E, seed, scale=0.05, dtype=torch.bfloat16):
     g = torch.Generator().manual_seed(seed)
     mk = {"stablelm": lambda: StableLMMLPRef(M, I), "phi": lambda: PhiMLPRef(M, I),
           "qwen": lambda: QWenMLPRef(M, I), "qwen_bias": lambda: QWenMLPRef(M, I, bias=True)}[kind]
     exps = []
     for _ in range(E):
-        e = mk().to(torch.bfloat16)
+        e = mk().to(dtype)
         for p in e.parameters():
-            p.data = (torch.randn(p.shape, generator=g) * scale).to(torch.bfloat16)
+            p.data = (torch.randn(p.shape, generator=g) * scale).to(dtype)
         exps.append(e)
     return exps
 
 
-def _build_pair(kind, M, I, E, S_shape, cf, seed, noisy=False, training=True):
+def _build_pair(kind, M, I, E, S_shape, cf, seed, noisy=False, training=True, dtype=torch.bfloat16):
     """(oracle MoERef on CPU, product MoE on GPU) with identical parameters."""
     import moe_llava_amd
-    exps = _mk_experts(kind, M, I, E, seed)
+    exps = _mk_experts(kind, M, I, E, seed, dtype=dtype)
     ref = lit.MoERef(M, exps[0], num_experts=E, k=2, capacity_factor=cf, eval_capacity_factor=2.0,
                      min_capacity=0, top2_2nd_expert_sampling=noisy)
     for dst, src in zip(ref.deepspeed_moe.experts.deepspeed_experts, exps):
@@ -146,11 +146,11 @@ def _build_pair(kind, M, I, E, S_shape, cf, seed, noisy=False, training=True):
     missing = mine.load_state_dict(ref.state_dict(), strict=True)      # checkpoint-key ABI
     assert not missing.missing_keys and not missing.unexpected_keys
     for m in mine.deepspeed_moe.experts.deepspeed_experts:
-        m.to(torch.bfloat16)
+        m.to(dtype)
     mine = mine.to(DEV)
     ref.train(training)
     mine.train(training)
-    x = torch.randn(*S_shape, M, generator=g).to(torch.bfloat16)
+    x = torch.randn(*S_shape, M, generator=g).to(dtype)
     return ref, mine, x
 
 
@@ -195,6 +195,58 @@ def test_moe_layer_vs_literal_oracle(kind, M, I, E, shape, cf, noisy):
     dead = (slot < 0).all(1)
     if dead.any():
         assert float(out.cpu().reshape(-1, M)[dead].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kind,M,I,E,shape,cf,wg16", [
+    ("stablelm", 128, 320, 4, (3, 111), 1.5, False),
+    ("stablelm", 256, 384, 4, (1, 5), 1.0, True),          # decode size: the weight-streaming kernel
+    ("qwen_bias", 64, 192, 8, (1, 300), 0.5, True),
+    ("phi", 128, 256, 4, (2, 130), 1.5, True),
+    ("phi", 64, 576, 8, (1, 257), 1.0, False),
+])
+@pytest.mark.parametrize("noisy", [False, True])
+def test_moe_layer_fp16_vs_literal_oracle(kind, M, I, E, shape, cf, wg16, noisy):
+    """The reference's inference loader builds the model in fp16 (moellava/model/builder.py:70, :475 model.to(float16);
+    serve/cli.py:67-69): the same block in fp16 -- fp16 MFMA, fp16 rounding points, gate in fp32 from (optionally fp16)
+    gate weights -- against the literal oracle run in fp16 on the CPU, to the same bars as bf16."""
+    ref, mine, x = _build_pair(kind, M, I, E, shape, cf, seed=9, noisy=noisy, training=False, dtype=torch.float16)
+    if wg16:                                               # model.to(torch.float16) casts the gate weight too
+        mine = mine.to(torch.float16)
+        ref.deepspeed_moe.gate.wg.weight.data = ref.deepspeed_moe.gate.wg.weight.data.to(torch.float16).float()
+        assert mine.deepspeed_moe.gate.wg.weight.dtype == torch.float16
+    S = x.numel() // M
+    if noisy:
+        noise = lit.gumbel_noise((S, E), 98)
+        mine.deepspeed_moe.gate.noise_override = noise.to(DEV)
+        ref.deepspeed_moe.gate.noise = noise
+    with torch.no_grad():
+        out, l_aux, exp_counts = mine(x.to(DEV))
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float16 and out.shape == x.shape and l_aux.dtype == torch.float32
+    lg = mine.deepspeed_moe.gate.last_logits.cpu()
+    ref_lg = torch.nn.functional.linear(x.reshape(-1, M).float(), ref.deepspeed_moe.gate.wg.weight.float())
+    assert lg.dtype == torch.float32 and torch.allclose(lg, ref_lg, atol=1e-4, rtol=1e-4)
+    ref.deepspeed_moe.gate.logits_override = lg
+    with torch.no_grad():
+        r_out, r_laux, r_counts = ref(x)
+    assert torch.equal(exp_counts.cpu(), r_counts) and abs(float(l_aux) - float(r_laux)) <= 1e-5
+    r = mine.deepspeed_moe.last_routing
+    want = ix.route_top2(lg, r.capacity, noise if noisy else None)
+    assert torch.equal(r.slot.cpu(), want["slot"]) and torch.equal(r.expert_idx.cpu(), want["expert_idx"])
+    # fp16 carries 3 more mantissa bits than bf16: the same bar is loose here, the printed numbers show the margin
+    assert_out_close(f"fp16 {kind} M{M} I{I} E{E} S{S} noisy={noisy}", out.cpu(), r_out)
+
+
+def test_fp16_is_forward_only_and_dtypes_must_agree():
+    ref, mine, x = _build_pair("stablelm", 64, 128, 4, (1, 40), 1.0, seed=2, dtype=torch.float16)
+    with pytest.raises(NotImplementedError):                  # training runs in bf16, as the reference's scripts do
+        mine(x.to(DEV).requires_grad_(True))
+    with pytest.raises(TypeError):                            # bf16 activations into fp16 experts
+        with torch.no_grad():
+            mine(x.to(DEV).to(torch.bfloat16))
+    with pytest.raises(TypeError):
+        with torch.no_grad():
+            mine(x.to(DEV).float())
 
 
 def test_top2_ignores_used_token_and_eval_ignores_jitter():
@@ -255,7 +307,7 @@ def test_cfg1_block_vs_index_oracle(kind, M, I):
     assert_out_close(f"cfg1 {kind}", got, want)
 
 
-def _full_size_check(kind, M, I, E, B, T, cf, stress=False):
+def _full_size_check(kind, M, I, E, B, T, cf, stress=False, dtype=torch.bfloat16):
     """Size-independent properties at a BASELINE shape instead of a full CPU run: determinism, counts, capacity,
     perm = inverse of (expert, slot), routing equal to the index oracle given the kernel's logits, rows that lost
     both choices exactly zero, and a sample of output rows against the oracle expert MLPs."""
@@ -265,14 +317,14 @@ def _full_size_check(kind, M, I, E, B, T, cf, stress=False):
     torch.manual_seed(0)
     moe = moe_llava_amd.MoE(M, mk[0](M, I), num_experts=E, k=2, capacity_factor=cf,
                             eval_capacity_factor=2.0, min_capacity=0, top2_2nd_expert_sampling=False)
-    moe = moe.to(torch.bfloat16)
+    moe = moe.to(dtype)
     for p in moe.deepspeed_moe.experts.parameters():
         p.data.normal_(0, 0.02)
     moe.deepspeed_moe.gate.wg.weight.data.normal_(0, 0.2)
     if stress:                                         # SURVEY 8d capacity-drop stress: expert 0 overflows
         moe.deepspeed_moe.gate.wg.weight.data[0] += 0.05
     moe = moe.to(DEV).train()
-    x = torch.randn(B, T, M, device=DEV).to(torch.bfloat16)
+    x = torch.randn(B, T, M, device=DEV).to(dtype)
     x[:, : (T * 4) // 5] += 0.5                        # "image" rows skew the router (drops happen)
     with torch.no_grad():
         out1, l1, c1 = moe(x)
@@ -309,13 +361,13 @@ def _full_size_check(kind, M, I, E, B, T, cf, stress=False):
     # sampled rows against the oracle MLPs
     sample = torch.randperm(S, generator=torch.Generator().manual_seed(1))[:48]
     sub = {k: (v[sample] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == S else v) for k, v in ref.items()}
-    cpu_experts = [mk[1](M, I).to(torch.bfloat16) for _ in range(E)]
+    cpu_experts = [mk[1](M, I).to(dtype) for _ in range(E)]
     for ce, ge in zip(cpu_experts, moe.deepspeed_moe.experts.deepspeed_experts):
         ce.load_state_dict({k: v.cpu() for k, v in ge.state_dict().items()})
     with torch.no_grad():
         want = ix.moe_forward_index(x.reshape(-1, M)[sample.to(DEV)].cpu(), sub, cpu_experts)
     got = o[sample.to(DEV)].cpu()
-    assert_out_close(f"{kind} M{M} I{I} E{E} S{S} sampled rows", got, want)
+    assert_out_close(f"{kind} M{M} I{I} E{E} S{S} {dtype} sampled rows", got, want)
     return r
 
 
@@ -323,6 +375,11 @@ def test_full_size_properties_cfg2():
     """BASELINE config 2: StableLM-1.6B-4e block, batch 32 -> S = 22 528."""
     r = _full_size_check("stablelm", 2048, 5632, 4, 32, 704, 1.5)
     assert r.capacity == 16896
+
+
+def test_full_size_properties_cfg2_fp16():
+    """Config 2's shape in the reference's inference dtype (fp16, builder.py:70): the 256 x 256 fp16 MFMA tile."""
+    _full_size_check("stablelm", 2048, 5632, 4, 32, 704, 1.5, dtype=torch.float16)
 
 
 def test_full_size_properties_cfg3_phi_rank_share():
@@ -615,7 +672,7 @@ def test_persistent_launch_equals_one_block_per_tile(epilogue):
             h = torch.zeros(R, N, dtype=torch.bfloat16, device=DEV)
             rc = lib.moe_grouped_gemm_fwd(epilogue, x.data_ptr(), M, perm.data_ptr(), 1, w1.data_ptr(),
                                           b1.data_ptr() if epilogue == 2 else None, offs.data_ptr(), E, E,
-                                          R, M, N, -1, h.data_ptr(), N, st)
+                                          R, M, N, -1, h.data_ptr(), N, 0, st)
             assert rc == 0, lib.moe_last_error()
             torch.cuda.synchronize()
             outs.append(h)

@@ -52,11 +52,11 @@ libs = {v: load(v) for v in a.variants}
 
 def fc1(lib):
     w1 = w1s[calls[0] % a.cold]; calls[0] += 1
-    rc = lib.moe_grouped_gemm_fwd(1, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), None, offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, st)
+    rc = lib.moe_grouped_gemm_fwd(1, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), None, offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, 0, st)
     assert rc == 0, lib.moe_last_error()
 def fc2(lib):
     w2 = w2s[calls[1] % a.cold]; calls[1] += 1
-    rc = lib.moe_grouped_gemm_fwd(0, h.data_ptr(), I + P, None, 0, w2.data_ptr(), None, offs.data_ptr(), E, E, R, I, M, -1, y.data_ptr(), M, st)
+    rc = lib.moe_grouped_gemm_fwd(0, h.data_ptr(), I + P, None, 0, w2.data_ptr(), None, offs.data_ptr(), E, E, R, I, M, -1, y.data_ptr(), M, 0, st)
     assert rc == 0, lib.moe_last_error()
 
 shapes = {"fc1": (fc1, 2.0 * R * 2 * I * M), "fc2": (fc2, 2.0 * R * M * I)}
