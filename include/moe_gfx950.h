@@ -163,8 +163,11 @@ int moe_routing_top1_fwd(const float *logits, const float *noise, uint64_t noise
  *   b1           [n_experts_local, N1] bf16 or NULL
  *   w2           [n_experts_local, M, I] bf16
  *   b2           [n_experts_local, M] bf16 or NULL
- *   group_offsets [G+1] int32 on the device
- *   max_rows     host upper bound of group_offsets[G] (sizes the grid and the workspace)
+ *   group_offsets [G+1] int32 on the device.  group_offsets[0] need not be 0: rows are ABSOLUTE indices into a (without a
+ *                gather index), h_ws and y, so several calls can each process their groups of one shared set of buffers
+ *                (the chunks of the expert-parallel exchange); rows outside [group_offsets[0], group_offsets[G]) are untouched
+ *   max_rows     host upper bound of group_offsets[G] - group_offsets[0] (sizes the grid); h_ws and y must cover
+ *                group_offsets[G] rows
  *   n_gated      SWIGLU only: hidden channels c >= n_gated skip the SiLU, h[c] = 1 * (Wb x)[c] -- the fork's RePaMLP
  *                experts, torch.where(mask, silu(gate), 1) * up with a prefix mask
  *                (moellava/model/language_model/llava_stablelm_moe.py:632-638,649-655; llava_qwen_moe.py:715-721).
@@ -201,6 +204,17 @@ int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t
  * (replaces the dispatch einsum in front of _AllToAll). */
 int moe_gather_rows_fwd(const void *src, const int32_t *gather, int gather_shift,
                         const int32_t *n_rows_dev, int max_rows, int M, void *dst, void *stream);
+
+/* moe_ep_chunk_rows_fwd: the send / return buffers of the CHUNKED expert-parallel exchange (the all-to-all of chunk c + 1
+ * travels while the grouped FFN of chunk c runs; SURVEY 8e, replaces the dispatch einsum + _AllToAll of rows a6-a7 for
+ * ep_size > 1).  Chunk c of n_chunks holds rows [k_e*c/n, k_e*(c+1)/n) of each of the E experts' k_e kept rows
+ * (k_e = expert_offsets[e+1] - expert_offsets[e], read on the device), experts in order inside a chunk, chunks in order.
+ *   unpack = 0: dst[chunk-major position of p] = src[gather ? gather[p] >> gather_shift : p]   for compact rows p
+ *   unpack = 1: dst[p] = src[chunk-major position of p]          (gather must be NULL)
+ * Rows of M 16-bit elements (a copy: bf16 and fp16 alike).  n_chunks = 1 is the plain expert-major order of
+ * moe_gather_rows_fwd.  M % 8 == 0, max_rows = host bound of expert_offsets[E].  One launch. */
+int moe_ep_chunk_rows_fwd(const void *src, const int32_t *gather, int gather_shift, const int32_t *expert_offsets,
+                          int E, int n_chunks, int unpack, int max_rows, int M, void *dst, void *stream);
 
 /* moe_combine_fwd: out[s] = bf16( float(bf16(w[s,0])) * y[pos(s,0)] + float(bf16(w[s,1])) * y[pos(s,1)] ),
  * pos(s,j) = expert_offsets[expert_idx[s,j]] + slot[s,j]; a dropped choice contributes 0.

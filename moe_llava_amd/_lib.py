@@ -42,6 +42,8 @@ _SIGNATURES = [
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
       c_int, c_void_p, c_int64, c_int, c_void_p]),
     ("moe_gather_rows_fwd", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    ("moe_ep_chunk_rows_fwd", c_int,
+     [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("moe_combine_fwd", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     ("moe_block_top2_fwd", c_int,

@@ -20,16 +20,20 @@ namespace moe {
 // activation forward / backward
 // ------------------------------------------------------------------------------------------------
 template <int ACT>
-__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t *__restrict__ ab, const int *__restrict__ n_rows_dev,
-                                                      int max_rows, int I, int n_gated, bf16_t *__restrict__ h) {
-    int n = *n_rows_dev;
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t *__restrict__ ab, const int *__restrict__ group_offsets,
+                                                      int G, int max_rows, int I, int n_gated, bf16_t *__restrict__ h) {
+    // rows [group_offsets[0], group_offsets[G]): the groups of one call need not start at row 0 (chunks of the
+    // expert-parallel exchange share one buffer)
+    const long long r0 = group_offsets[0];
+    int n = group_offsets[G] - (int)r0;
     if (n > max_rows) n = max_rows;
     const int chunks = I >> 3;
     const long long total = (long long)n * chunks;
     const int N1 = (ACT == MOE_ACT_SWIGLU) ? 2 * I : I;
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-        const long long r = t / chunks;
-        const int c = (int)(t - r * chunks);
+        const long long rl = t / chunks;
+        const int c = (int)(t - rl * chunks);
+        const long long r = r0 + rl;
         const bf16_t *row = ab + r * N1 + c * 8;
         float a[8], o[8];
         unpack8(*reinterpret_cast<const uint4 *>(row), a);
@@ -402,16 +406,16 @@ int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst
     return check_launch("transpose_rows_kernel(batched)");
 }
 
-int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, int n_gated, bf16_t *h,
+int launch_act_fwd(int act, const bf16_t *ab, const int *group_offsets, int G, int max_rows, int I, int n_gated, bf16_t *h,
                    hipStream_t st) {
     if (n_gated < 0 || n_gated > I) n_gated = I;
     const int grid = ew_grid((long long)max_rows * (I >> 3));
     if (act == MOE_ACT_SWIGLU)
-        hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_SWIGLU>), dim3(grid), dim3(256), 0, st, ab, n_rows_dev, max_rows, I, n_gated,
-                           h);
+        hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_SWIGLU>), dim3(grid), dim3(256), 0, st, ab, group_offsets, G, max_rows, I,
+                           n_gated, h);
     else
-        hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_GELU_NEW>), dim3(grid), dim3(256), 0, st, ab, n_rows_dev, max_rows, I, n_gated,
-                           h);
+        hipLaunchKernelGGL((act_fwd_kernel<MOE_ACT_GELU_NEW>), dim3(grid), dim3(256), 0, st, ab, group_offsets, G, max_rows, I,
+                           n_gated, h);
     return check_launch("act_fwd_kernel");
 }
 

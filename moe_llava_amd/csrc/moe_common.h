@@ -118,6 +118,12 @@ __device__ __forceinline__ void round2(float &x, float &y) {
     Elt<DT>::unpack2(Elt<DT>::pack2(x, y), x, y);
 }
 template <int DT>
+__device__ __forceinline__ moe_f32x2_t round2v(moe_f32x2_t v) {
+    float x, y;
+    Elt<DT>::unpack2(Elt<DT>::pack2(v.x, v.y), x, y);
+    return moe_f32x2_t{x, y};
+}
+template <int DT>
 __device__ __forceinline__ void unpack8_t(const uint4 v, float *f) {
     Elt<DT>::unpack2(v.x, f[0], f[1]);
     Elt<DT>::unpack2(v.y, f[2], f[3]);
@@ -178,6 +184,27 @@ __device__ __forceinline__ float gelu_new_r(float x) {
     const float t5 = E::round(1.0f + t4);
     const float t6 = E::round(0.5f * x);
     return E::round(t6 * t5);
+}
+
+// gelu_new on TWO elements at once, same rounding points as gelu_new_r: the seven intermediate roundings go through one
+// packed convert each (v_cvt_pk_*: half the converts of the scalar form), the arithmetic through packed fp32
+// instructions where the compiler finds them; the LAST rounding is left to the caller's pack2 (rounding twice is the
+// identity).  exp(2u) = exp2(u * 2 log2(e)): the same product as __expf(2u) (scaling by 2 commutes with rounding).
+template <int DT>
+__device__ __forceinline__ void gelu_new_pair(float &a, float &b) {
+    const moe_f32x2_t x = {a, b};
+    moe_f32x2_t p = round2v<DT>(x * x * x);
+    p = round2v<DT>(p * 0.044715f);
+    p = round2v<DT>(x + p);
+    p = round2v<DT>(p * 0.7978845608028654f);
+    moe_f32x2_t t;
+    t.x = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(p.x * 2.885390081777927f));
+    t.y = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(p.y * 2.885390081777927f));
+    t = round2v<DT>(t);
+    t = round2v<DT>(t + 1.0f);
+    const moe_f32x2_t h = round2v<DT>(x * 0.5f) * t;
+    a = h.x;
+    b = h.y;
 }
 
 // Backward of the activations on 8 packed elements, with the bf16 rounding points of the autograd graph of the
@@ -255,7 +282,7 @@ int launch_transpose_batched(const bf16_t *src, int B, int R, int C, bf16_t *dst
 // dW_e[R, N] = A[rows of expert e]^T @ B[rows of expert e] (moe_wgrad.hip)
 int launch_wgrad_tn(const bf16_t *a, long long lda, const bf16_t *b, long long ldb, const int *group_offsets, int G,
                     int n_experts, int max_rows, int R, int N, bf16_t *out, hipStream_t st);
-int launch_act_fwd(int act, const bf16_t *ab, const int *n_rows_dev, int max_rows, int I, int n_gated, bf16_t *h,
+int launch_act_fwd(int act, const bf16_t *ab, const int *group_offsets, int G, int max_rows, int I, int n_gated, bf16_t *h,
                    hipStream_t st);
 // out[e, n] = sum over the rows of expert e's groups of d[r, n]  (fp32, zeroed here)
 int launch_bias_grad(const bf16_t *d, const int *group_offsets, int G, int n_experts_local, int max_rows, int N, float *out,

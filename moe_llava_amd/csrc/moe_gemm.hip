@@ -131,6 +131,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
 #endif
         const int RS = p.rs;
+        if (RS <= 0) {
+            // Group-major order (weight-streaming regime, a few row tiles per group): all row tiles of one (group, column
+            // tile) are consecutive, the column tiles of a group follow each other.  The blocks an XCD runs together then
+            // share their W panel through its L2 in step -- with fixed super-rows a group's W panels were fetched once per
+            // super-row that the group straddles (config 1: 1.7x the weight bytes from beyond L2).
+            int base = 0;
+            for (int g = 0; g < p.G; ++g) {
+                const int b = p.group_offsets[g], e = p.group_offsets[g + 1];
+                const int nt = (e - b + BM - 1) / BM;
+                if (swz < base + nt * CT) {
+                    const int local = swz - base;
+                    c.ct = local / nt;
+                    c.row_begin = b + (local - c.ct * nt) * BM;
+                    c.row_end = e;
+                    c.expert = g % p.n_experts;
+                    return true;
+                }
+                base += nt * CT;
+            }
+            return false;
+        }
         const int per_sr = RS * CT;
         const int sr = swz / per_sr;
         const int rem = swz - sr * per_sr;
@@ -441,8 +462,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                     for (int j = 0; j < 4; ++j) v[j] = acc[nf][mf][j] + bv[j];  // bf16 output of the Linear (rounded below)
                     if (EPI == EPI_GELU_NEW) {
                         round2<DT>(v[0], v[1]); round2<DT>(v[2], v[3]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = gelu_new_r<DT>(v[j]);
+                        gelu_new_pair<DT>(v[0], v[1]);   // the last rounding is pack2's below
+                        gelu_new_pair<DT>(v[2], v[3]);
                     }
                     uint2 o;
                     o.x = E::pack2(v[0], v[1]);
@@ -580,6 +601,13 @@ static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     // super-row height: 4 row tiles (an XCD's 32 CUs then work on 4 x 8 tiles); launches with few column tiles (fc2 of
     // config 2: 8) measured 2 % faster with 3 (same-process A/B: 811 -> 793 us; fc1 with 44 column tiles 0.7 % slower)
     p.rs = GEMM_RS > 0 ? GEMM_RS : (p.col_tiles <= 8 ? 3 : 4);
+    // small row tiles = few rows per group = weight streaming: group-major tile order (see map_tile); MOE_GEMM_ORDER=0/1 forces
+    // super-rows / group-major for A/B runs
+    if (BM < 256) p.rs = 0;
+    if (const char *env = getenv("MOE_GEMM_ORDER")) {
+        if (env[0] == '0' && p.rs == 0) p.rs = 4;
+        if (env[0] == '1') p.rs = 0;
+    }
     long long grid = (long long)p.max_row_tiles * p.col_tiles;
     if (grid <= 0) return 0;
     if (grid > 0x7fffffffLL) return fail(MOE_ERR_SHAPE, "grouped_gemm: grid too large");
@@ -740,7 +768,7 @@ extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, con
                               M, N1, -1, ab, N1, MOE_DTYPE_BF16, stream);
     if (rc) return rc;
     if (max_rows == 0) return 0;
-    rc = launch_act_fwd(act, (const bf16_t *)ab, group_offsets + G, max_rows, I, n_gated, (bf16_t *)h, (hipStream_t)stream);
+    rc = launch_act_fwd(act, (const bf16_t *)ab, group_offsets, G, max_rows, I, n_gated, (bf16_t *)h, (hipStream_t)stream);
     if (rc) return rc;
     return moe_grouped_gemm_fwd(MOE_EPI_PLAIN, h, I, nullptr, 0, w2, b2, group_offsets, G, n_experts_local, max_rows, I, M,
                                 -1, y, M, MOE_DTYPE_BF16, stream);

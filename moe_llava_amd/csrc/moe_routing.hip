@@ -494,6 +494,50 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t *__restri
     }
 }
 
+// Expert-parallel exchange in chunks: position of compact row p in the CHUNK-MAJOR send order.  Chunk c holds rows
+// [k_e * c / C, k_e * (c + 1) / C) of every expert's k_e kept rows (so both sides of the exchange derive all split sizes
+// from the kept-count matrix); inside a chunk the experts follow each other in order.  Computed per row from the
+// device-side expert_offsets: no host-built index arrays.
+__device__ __forceinline__ int chunk_major_pos(const int *__restrict__ offs, int E, int C, int p) {
+    int e = 0;
+    while (e + 1 < E && offs[e + 1] <= p) ++e;     // rows of experts with no kept rows are skipped: offs[e+1] == offs[e]
+    const int i = p - offs[e];
+    const long long ke = offs[e + 1] - offs[e];
+    int c = (int)(((long long)i * C + C - 1) / (ke > 0 ? ke : 1));   // first guess, then fix: edges are floor(k*c/C)
+    if (c > C - 1) c = C - 1;
+    while (c > 0 && (int)(ke * c / C) > i) --c;
+    while (c + 1 < C && (int)(ke * (c + 1) / C) <= i) ++c;
+    int pos = i - (int)(ke * c / C);
+    for (int q = 0; q < E; ++q) {
+        const long long kq = offs[q + 1] - offs[q];
+        pos += (int)(kq * c / C);                                     // everything in earlier chunks
+        if (q < e) pos += (int)(kq * (c + 1) / C) - (int)(kq * c / C);  // earlier experts inside this chunk
+    }
+    return pos;
+}
+
+// unpack = 0: dst[chunk_major_pos(p)] = src[gather[p] >> shift]   (send buffer from the tokens)
+// unpack = 1: dst[p] = src[chunk_major_pos(p)]                    (returned rows back to compact expert-major order)
+__global__ __launch_bounds__(256) void chunk_rows_kernel(const bf16_t *__restrict__ src, const int *__restrict__ gather,
+                                                         int gather_shift, const int *__restrict__ offs, int E, int C,
+                                                         int unpack, int max_rows, int M, bf16_t *__restrict__ dst) {
+    int n = offs[E];
+    if (n > max_rows) n = max_rows;
+    const int chunks = M >> 3;
+    __shared__ int s_pos;
+    for (int p = blockIdx.x; p < n; p += gridDim.x) {
+        if (threadIdx.x == 0) s_pos = chunk_major_pos(offs, E, C, p);
+        __syncthreads();
+        const size_t cm = (size_t)s_pos;
+        const size_t srow = unpack ? cm : (gather ? (size_t)(gather[p] >> gather_shift) : (size_t)p);
+        const size_t drow = unpack ? (size_t)p : cm;
+        const uint4 *sp = reinterpret_cast<const uint4 *>(src + srow * M);
+        uint4 *dp = reinterpret_cast<uint4 *>(dst + drow * M);
+        for (int c = threadIdx.x; c < chunks; c += blockDim.x) dp[c] = sp[c];
+        __syncthreads();
+    }
+}
+
 template <int TOPK, int DT>
 __global__ __launch_bounds__(256) void combine_kernel(const bf16_t *__restrict__ y, const int *__restrict__ expert_idx,
                                                       const int *__restrict__ slot, const float *__restrict__ weight,
@@ -789,6 +833,22 @@ extern "C" int moe_gather_rows_fwd(const void *src, const int32_t *gather, int g
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)src, gather,
                        gather_shift, n_rows_dev, max_rows, M, (bf16_t *)dst);
     return check_launch("gather_rows_kernel");
+}
+
+extern "C" int moe_ep_chunk_rows_fwd(const void *src, const int32_t *gather, int gather_shift,
+                                     const int32_t *expert_offsets, int E, int n_chunks, int unpack, int max_rows, int M,
+                                     void *dst, void *stream) {
+    if (!src || !expert_offsets || !dst) return fail(MOE_ERR_ARG, "moe_ep_chunk_rows_fwd: null pointer");
+    if (max_rows < 0 || M <= 0 || (M & 7) || gather_shift < 0 || gather_shift > 1 || E < 1 || E > 4096 || n_chunks < 1 ||
+        n_chunks > 64 || (unpack != 0 && unpack != 1) || (unpack && gather))
+        return fail(MOE_ERR_SHAPE, "moe_ep_chunk_rows_fwd: need M%%8==0, gather_shift in {0,1}, 1<=E<=4096, 1<=n_chunks<=64, "
+                                   "no gather index when unpacking");
+    if (!aligned16(src) || !aligned16(dst)) return fail(MOE_ERR_ALIGN, "moe_ep_chunk_rows_fwd: src / dst not 16-byte aligned");
+    if (max_rows == 0) return 0;
+    const int grid = max_rows < 8192 ? max_rows : 8192;
+    hipLaunchKernelGGL(chunk_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)src, gather,
+                       gather_shift, expert_offsets, E, n_chunks, unpack, max_rows, M, (bf16_t *)dst);
+    return check_launch("chunk_rows_kernel");
 }
 
 extern "C" int moe_combine_fwd(const void *y, const int32_t *expert_idx, const int32_t *slot, const float *weight,

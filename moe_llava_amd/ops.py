@@ -311,13 +311,28 @@ def _check_ffn_weights(act, a, w1, b1, w2, b2):
     return M, I, n_local
 
 
+def _check_out(t: Tensor, name: str, like: Tensor, cols: int) -> None:
+    if (not isinstance(t, Tensor) or t.dtype != like.dtype or t.device != like.device or t.dim() != 2
+            or t.shape[1] != cols or not t.is_contiguous()):
+        raise ValueError(f"out[{name}]: need a contiguous [rows, {cols}] {like.dtype} tensor on {like.device}")
+
+
 def _expert_ffn_launch(act, a, gather_ptr, gather_shift, w1, b1, w2, b2, offs_ptr, G, max_rows, M, I, n_local, timer,
-                       n_gated):
+                       n_gated, out=None):
     dev = a.device
-    y = torch.empty((max(max_rows, 1), M), dtype=a.dtype, device=dev)
-    if max_rows == 0:
-        return y
-    h = torch.empty((max_rows, I), dtype=a.dtype, device=dev)
+    if out is not None:
+        # caller-provided (y, h) indexed by ABSOLUTE compact row (the chunks of the expert-parallel exchange write their
+        # rows of one shared pair of buffers); the caller guarantees they cover every row the group offsets name
+        y, h = out
+        _check_out(y, "y", a, M)
+        _check_out(h, "h", a, I)
+        if max_rows == 0:
+            return y
+    else:
+        y = torch.empty((max(max_rows, 1), M), dtype=a.dtype, device=dev)
+        if max_rows == 0:
+            return y
+        h = torch.empty((max_rows, I), dtype=a.dtype, device=dev)
     dt = _dt(a)
     lib = _lib.load()
     b1p = b1.data_ptr() if b1 is not None else None
@@ -347,9 +362,10 @@ def _expert_ffn_launch(act, a, gather_ptr, gather_shift, w1, b1, w2, b2, offs_pt
 def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
                w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
                group_offsets: Tensor, max_rows: int, timer: Optional["PhaseTimer"] = None,
-               n_gated: int = -1) -> Tensor:
-    """Grouped expert MLP over compact rows; returns y [max_rows, M] bf16 (rows past the device-side
-    group_offsets[G] are left unwritten)."""
+               n_gated: int = -1, out=None) -> Tensor:
+    """Grouped expert MLP over compact rows; returns y [max_rows, M] (rows past the device-side
+    group_offsets[G] are left unwritten).  ``out=(y, h)``: write into these buffers instead (indexed by the absolute
+    rows the group offsets name; ``max_rows`` then only bounds the number of rows of THIS call)."""
     M, I, n_local = _check_ffn_weights(act, a, w1, b1, w2, b2)
     _need(group_offsets, "group_offsets", torch.int32, 1)
     G = group_offsets.numel() - 1
@@ -365,7 +381,7 @@ def expert_ffn(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
         if t is not None and t.device != a.device:
             raise ValueError("all operands must be on the same device")
     return _expert_ffn_launch(act, a, gather.data_ptr() if gather is not None else None, gather_shift, w1, b1, w2, b2,
-                              group_offsets.data_ptr(), G, max_rows, M, I, n_local, timer, n_gated)
+                              group_offsets.data_ptr(), G, max_rows, M, I, n_local, timer, n_gated, out)
 
 
 def expert_ffn_routed(act: int, x: Tensor, r: Routing, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
@@ -451,6 +467,32 @@ def gather_rows(src: Tensor, gather: Tensor, gather_shift: int, n_rows_dev: Tens
     return dst
 
 
+def ep_chunk_rows(src: Tensor, gather: Optional[Tensor], gather_shift: int, expert_offsets: Tensor, n_chunks: int,
+                  unpack: bool, max_rows: int, out: Optional[Tensor] = None) -> Tensor:
+    """Send buffer (``unpack=False``: rows gathered through ``gather`` and laid out chunk-major) or returned rows put back
+    in compact expert-major order (``unpack=True``) of the chunked expert-parallel exchange; positions are computed on the
+    device from ``expert_offsets`` ([E+1] int32)."""
+    _need(src, "src", HALF_DTYPES, 2)
+    _need(expert_offsets, "expert_offsets", torch.int32, 1)
+    if gather is not None:
+        _need(gather, "gather", torch.int32, 1)
+        if gather.numel() < max_rows:
+            raise ValueError("gather shorter than max_rows")
+    E = expert_offsets.numel() - 1
+    M = src.shape[1]
+    if out is None:
+        out = torch.empty((max(max_rows, 1), M), dtype=src.dtype, device=src.device)
+    elif out.shape[0] < max_rows or out.shape[1] != M or out.dtype != src.dtype or not out.is_contiguous():
+        raise ValueError("out does not match")
+    lib = _lib.load()
+    with _on(src.device):
+        rc = lib.moe_ep_chunk_rows_fwd(src.data_ptr(), gather.data_ptr() if gather is not None else None, gather_shift,
+                                       expert_offsets.data_ptr(), E, int(n_chunks), int(bool(unpack)), max_rows, M,
+                                       out.data_ptr(), _stream_ptr(src))
+    _lib.check(rc, "moe_ep_chunk_rows_fwd")
+    return out
+
+
 def combine(y: Tensor, r: Routing, S: int, M: int) -> Tensor:
     """out[s] = sum_j bf16(w[s,j]) * y[pos(s,j)]  (the ``sec,ecm->sm`` einsum)."""
     _need(y, "y", HALF_DTYPES, 2)
@@ -481,8 +523,9 @@ def _ffn_shapes(act, a, w1, w2):
 
 def expert_ffn_train(act: int, a: Tensor, gather: Optional[Tensor], gather_shift: int,
                      w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
-                     group_offsets: Tensor, max_rows: int, n_gated: int = -1):
-    """``expert_ffn`` that keeps what the backward needs: returns (y, ab, h)."""
+                     group_offsets: Tensor, max_rows: int, n_gated: int = -1, out=None):
+    """``expert_ffn`` that keeps what the backward needs: returns (y, ab, h).  ``out=(y, ab, h)``: write into these
+    buffers (absolute compact rows, as in ``expert_ffn``)."""
     _need(a, "a", torch.bfloat16, 2)
     _need(w1, "w1", torch.bfloat16, 3)
     _need(w2, "w2", torch.bfloat16, 3)
@@ -497,9 +540,15 @@ def expert_ffn_train(act: int, a: Tensor, gather: Optional[Tensor], gather_shift
         raise ValueError("a has fewer rows than max_rows")
     dev = a.device
     rows = max(max_rows, 1)
-    y = torch.empty((rows, M), dtype=torch.bfloat16, device=dev)
-    ab = torch.empty((rows, n1), dtype=torch.bfloat16, device=dev)
-    h = torch.empty((rows, I), dtype=torch.bfloat16, device=dev)
+    if out is not None:
+        y, ab, h = out
+        _check_out(y, "y", a, M)
+        _check_out(ab, "ab", a, n1)
+        _check_out(h, "h", a, I)
+    else:
+        y = torch.empty((rows, M), dtype=torch.bfloat16, device=dev)
+        ab = torch.empty((rows, n1), dtype=torch.bfloat16, device=dev)
+        h = torch.empty((rows, I), dtype=torch.bfloat16, device=dev)
     if max_rows == 0:
         return y, ab, h
     lib = _lib.load()

@@ -274,7 +274,7 @@ class MOELayer(nn.Module):
         ng = self.experts.n_gated
         shift = r.top_k - 1                      # perm holds token * top_k + choice
         saved = None
-        if self.ep_size == 1 and not (self.force_exchange and self.ep_group is not None):
+        if local:
             if save:
                 y, ab, h = ops.expert_ffn_train(act, x, r.perm, shift, w1, b1, w2, b2, r.expert_offsets, r.max_rows, ng)
                 saved = dict(a=x, gather=r.perm, shift=shift, ab=ab, h=h, offs=r.expert_offsets, rows=r.max_rows)
@@ -300,15 +300,12 @@ class MOELayer(nn.Module):
                 saved["act"], saved["a"], saved["gather"], saved["shift"], saved["w1"], saved["w2"], saved["ab"],
                 saved["h"], dy, saved["offs"], saved["rows"], saved["has_b1"], saved["has_b2"], saved["ng"])
         else:
-            n_send, n_recv = saved["n_send"], saved["n_recv"]
-            dy_recv = torch.empty((max(n_recv, 1), M), dtype=torch.bfloat16, device=x.device)
-            _all_to_all_rows(dy_recv[:n_recv], dy[:n_send], saved["recv_splits"], saved["send_splits"], self.ep_group)
+            plan = saved["plan"]
+            dy_recv = self._exchange_rows_chunked(dy, r, plan, to_experts=True)
             da_recv, dw1, db1, dw2, db2 = ops.expert_ffn_bwd(
                 saved["act"], saved["a"], None, 0, saved["w1"], saved["w2"], saved["ab"], saved["h"], dy_recv,
-                saved["offs"], n_recv, saved["has_b1"], saved["has_b2"], saved["ng"])
-            da_rows = torch.empty((max(n_send, r.max_rows, 1), M), dtype=torch.bfloat16, device=x.device)
-            _all_to_all_rows(da_rows[:n_send], da_recv[:n_recv], saved["send_splits"], saved["recv_splits"],
-                             self.ep_group)
+                saved["offs"], plan["n_recv"], saved["has_b1"], saved["has_b2"], saved["ng"])
+            da_rows = self._exchange_rows_chunked(da_recv, r, plan, to_experts=False)
         dlogits, dwg = ops.gate_bwd(x, saved["logits"], r, dweight, dl_aux)
         dx = ops.dispatch_bwd(da_rows, r, dlogits, self.gate.wg.weight.detach(), S, M)
         return dx, dwg, dw1, db1, dw2, db2
@@ -317,7 +314,14 @@ class MOELayer(nn.Module):
     def _expert_parallel(self, x: Tensor, r: ops.Routing, act, w1, b1, w2, b2, save: bool = False):
         """Expert-parallel exchange: rank q of the EP group owns experts [q*El, (q+1)*El).
         Only kept rows travel (variable-split all_to_all_single over RCCL), not upstream's capacity-padded
-        [E,C,M] block.  One host sync per call fetches the [ep, E] kept-count matrix that sizes the splits."""
+        [E,C,M] block.  One host sync per call fetches the [ep, E] kept-count matrix that sizes the splits; everything
+        per ROW (send order, return order) is computed on the device (``moe_ep_chunk_rows_fwd``).
+
+        The exchange is pipelined in C chunks (``_ep_chunks``): chunk c takes rows [c*k/C, (c+1)*k/C) of every (source
+        rank, expert) pair's k kept rows, so both sides derive all split sizes from the one count matrix.  The all-to-all
+        of chunk c+1 (and the return of chunk c-1) run on RCCL's stream while the grouped FFN of chunk c runs on the
+        compute stream.  Received rows sit in ONE buffer ordered (chunk, source, local expert): C*ep*El groups, group g
+        uses expert g % El -- which is also what the backward pass (one call over all groups) wants."""
         import torch.distributed as dist
         if self.ep_group is None:
             raise RuntimeError("ep_size > 1 but no expert-parallel group set: call MoE.set_deepspeed_parallelism() "
@@ -328,126 +332,151 @@ class MOELayer(nn.Module):
         me = dist.get_rank(self.ep_group)
         E = ep * El
         M = x.shape[1]
+        dev = x.device
         # every rank learns every rank's kept counts: [ep(src), E]; the one host sync of the call
-        kept_h = _all_gather_counts(r.kept_counts, ep, self.ep_group).to(torch.int64)
-        send_splits = kept_h[me].reshape(ep, El).sum(1).tolist()     # rows I send to each rank
-        recv_mat = kept_h[:, me * El:(me + 1) * El]                  # [src, le] rows I receive
-        recv_splits = recv_mat.sum(1).tolist()
-        n_send, n_recv = int(sum(send_splits)), int(sum(recv_splits))
-        self.last_ffn_rows = n_recv
-        self.last_ffn_launches = 1
-        chunks = _ep_chunks(n_send, n_recv)
-        if not save and chunks > 1:
-            return self._expert_parallel_chunked(x, r, act, w1, b1, w2, b2, kept_h, me, chunks), None
-        send = ops.gather_rows(x, r.perm, r.top_k - 1, r.expert_offsets[E:E + 1], n_send)
-        recv = torch.empty((max(n_recv, 1), M), dtype=x.dtype, device=x.device)
-        _all_to_all_rows(recv[:n_recv], send[:n_send], recv_splits, send_splits, self.ep_group)
-        # received rows are ordered (src, local expert): ep*El groups, group g uses expert g % El
-        offs_h = torch.zeros(ep * El + 1, dtype=torch.int32)
-        offs_h[1:] = torch.cumsum(recv_mat.reshape(-1), 0).to(torch.int32)
-        offs = offs_h.to(x.device, non_blocking=True)
+        k = _all_gather_counts(r.kept_counts, ep, self.ep_group).numpy().astype(np.int64)
+        n_send, n_recv = int(k[me].sum()), int(k[:, me * El:(me + 1) * El].sum())
+        C = _ep_chunks(n_send, n_recv, M, ep, self._ep_bandwidth(x))
+        edges = (k[:, :, None] * np.arange(C + 1, dtype=np.int64)) // C      # [src, e, C+1]
+        cnt = edges[:, :, 1:] - edges[:, :, :-1]                             # [src, e, c]
+        send_cnt = cnt[me].reshape(ep, El, C).sum(1)                         # [dest, c]
+        recv_cnt = cnt[:, me * El:(me + 1) * El, :]                          # [src, le, c]
+        send_edges = np.concatenate([[0], np.cumsum(send_cnt.sum(0))])       # chunk boundaries in the send buffer
+        recv_edges = np.concatenate([[0], np.cumsum(recv_cnt.sum((0, 1)))])  # ... and in the receive buffer
+        G1 = ep * El
+        # group offsets of the receive buffer, (chunk, source, local expert) order, in one host->device copy
+        offs_h = np.zeros(C * G1 + 1, dtype=np.int32)
+        offs_h[1:] = np.cumsum(recv_cnt.transpose(2, 0, 1).reshape(-1))
+        offs = torch.from_numpy(offs_h).to(dev, non_blocking=True)
+        self.last_ffn_rows, self.last_ffn_launches = n_recv, C
+        plan = dict(C=C, n_send=n_send, n_recv=n_recv, send_edges=send_edges, recv_edges=recv_edges,
+                    send_splits=[send_cnt[:, c].tolist() for c in range(C)],
+                    recv_splits=[recv_cnt[:, :, c].sum(1).tolist() for c in range(C)])
+        # send buffer: kept rows gathered through the dispatch index, chunk-major (device-side positions)
+        send = ops.ep_chunk_rows(x, r.perm, r.top_k - 1, r.expert_offsets, C, False, n_send)
+        rows = max(n_recv, 1)
+        recv = torch.empty((rows, M), dtype=x.dtype, device=dev)
+        works = [_all_to_all_rows_async(recv[recv_edges[c]:recv_edges[c + 1]], send[send_edges[c]:send_edges[c + 1]],
+                                        plan["recv_splits"][c], plan["send_splits"][c], self.ep_group) for c in range(C)]
+        I = w2.shape[2]
+        y_recv = torch.empty((rows, M), dtype=x.dtype, device=dev)
+        h = torch.empty((rows, I), dtype=x.dtype, device=dev)
+        ab = torch.empty((rows, w1.shape[1]), dtype=x.dtype, device=dev) if save else None
+        y_cm = torch.empty((max(n_send, 1), M), dtype=x.dtype, device=dev)   # returned rows, chunk-major
+        back = []
+        # The chunks' grouped FFNs alternate between the compute stream and a side stream: a chunk launch is only a few
+        # rounds of 256-row tiles (fc2: 1.4 rounds at the bench's shapes), and with two streams the next chunk's blocks
+        # fill the CUs that the tail of the previous launch leaves idle.
+        cur = torch.cuda.current_stream(dev) if x.is_cuda else None
+        two = cur is not None and C > 1 and os.environ.get("MOE_EP_STREAMS", "2") != "1"
+        if two:
+            side = self.__dict__.get("_side_stream")
+            if side is None or side.device != dev:
+                side = torch.cuda.Stream(device=dev)
+                self.__dict__["_side_stream"] = side
+            side.wait_stream(cur)                                  # the send buffer and the offsets are ready
+        ng = self.experts.n_gated
+        for c in range(C):
+            n_rc = int(recv_edges[c + 1] - recv_edges[c])
+            on_side = two and (c & 1)
+            with (torch.cuda.stream(side) if on_side else ops._NULL):
+                with (ops.stream_scope(recv) if two else ops._NULL):  # the launches follow the stream switch
+                    if works[c] is not None:
+                        works[c].wait()
+                    go = offs[c * G1:(c + 1) * G1 + 1]               # absolute row offsets of this chunk's groups
+                    if save:
+                        ops.expert_ffn_train(act, recv, None, 0, w1, b1, w2, b2, go, n_rc, ng, out=(y_recv, ab, h))
+                    else:
+                        ops.expert_ffn(act, recv, None, 0, w1, b1, w2, b2, go, n_rc, timer=self.timer, n_gated=ng,
+                                       out=(y_recv, h))
+                    back.append(_all_to_all_rows_async(y_cm[send_edges[c]:send_edges[c + 1]],
+                                                       y_recv[recv_edges[c]:recv_edges[c + 1]],
+                                                       plan["send_splits"][c], plan["recv_splits"][c], self.ep_group))
+        if two:
+            cur.wait_stream(side)
+        for w in back:
+            if w is not None:
+                w.wait()
+        # back to compact (expert-major) order, in a buffer the combine can index up to max_rows
+        y = torch.empty((max(n_send, r.max_rows, 1), M), dtype=x.dtype, device=dev)
+        ops.ep_chunk_rows(y_cm, None, 0, r.expert_offsets, C, True, n_send, out=y)
         saved = None
         if save:
-            y_recv, ab, h = ops.expert_ffn_train(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv, self.experts.n_gated)
-            saved = dict(a=recv, ab=ab, h=h, offs=offs, n_send=n_send, n_recv=n_recv, send_splits=send_splits,
-                         recv_splits=recv_splits)
-        else:
-            y_recv = ops.expert_ffn(act, recv, None, 0, w1, b1, w2, b2, offs, n_recv, timer=self.timer,
-                                    n_gated=self.experts.n_gated)
-        y = torch.empty((max(n_send, r.max_rows, 1), M), dtype=x.dtype, device=x.device)
-        _all_to_all_rows(y[:n_send], y_recv[:n_recv], send_splits, recv_splits, self.ep_group)
+            saved = dict(a=recv, ab=ab, h=h, offs=offs, plan=plan)
         return y, saved
 
+    def _exchange_rows_chunked(self, src_compact: Tensor, r: ops.Routing, plan, to_experts: bool) -> Tensor:
+        """Backward-pass exchanges along the forward route.  ``to_experts``: compact rows of this rank's tokens
+        (expert-major) -> receive-buffer order on the expert ranks; else the reverse.  Chunks go out back to back, so
+        chunk c+1 is on the wire while chunk c is unpacked (the compute between the two directions is one call)."""
+        C, n_send, n_recv = plan["C"], plan["n_send"], plan["n_recv"]
+        se, re_ = plan["send_edges"], plan["recv_edges"]
+        M = src_compact.shape[1]
+        dev = src_compact.device
+        if to_experts:
+            cm = ops.ep_chunk_rows(src_compact, None, 0, r.expert_offsets, C, False, n_send)
+            out = torch.empty((max(n_recv, 1), M), dtype=src_compact.dtype, device=dev)
+            works = [_all_to_all_rows_async(out[re_[c]:re_[c + 1]], cm[se[c]:se[c + 1]], plan["recv_splits"][c],
+                                            plan["send_splits"][c], self.ep_group) for c in range(C)]
+            for w in works:
+                if w is not None:
+                    w.wait()
+            return out
+        cm = torch.empty((max(n_send, 1), M), dtype=src_compact.dtype, device=dev)
+        works = [_all_to_all_rows_async(cm[se[c]:se[c + 1]], src_compact[re_[c]:re_[c + 1]], plan["send_splits"][c],
+                                        plan["recv_splits"][c], self.ep_group) for c in range(C)]
+        for w in works:
+            if w is not None:
+                w.wait()
+        out = torch.empty((max(n_send, r.max_rows, 1), M), dtype=src_compact.dtype, device=dev)
+        ops.ep_chunk_rows(cm, None, 0, r.expert_offsets, C, True, n_send, out=out)
+        return out
 
-def _ep_chunks(n_send: int, n_recv: int) -> int:
-    """Chunks the expert-parallel exchange is pipelined in (MOE_EP_CHUNKS overrides; 1 = one exchange each way)."""
-    import os
+    def _ep_bandwidth(self, x: Tensor) -> float:
+        """Per-peer all-to-all bandwidth of the EP group in GB/s, measured once (first expert-parallel forward, which
+        every rank of the group enters together): 8 MiB to every peer, second of two runs timed.  Sizes the chunking
+        of the exchange (``_ep_chunks``).  Not measurable on a gloo group or a single rank: returns 0 (= unknown)."""
+        bw = self.__dict__.get("_ep_bw")
+        if bw is not None:
+            return bw
+        import torch.distributed as dist
+        bw = 0.0
+        env = os.environ.get("MOE_EP_BW_GBS")
+        if env:
+            bw = float(env)
+        elif x.is_cuda and self.ep_size > 1 and not _group_is_gloo(self.ep_group):
+            per = 8 << 20
+            a = torch.empty(self.ep_size * per, dtype=torch.uint8, device=x.device)
+            b = torch.empty_like(a)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            for i in range(2):
+                ev[0].record()
+                dist.all_to_all_single(b, a, group=self.ep_group)
+                ev[1].record()
+            torch.cuda.synchronize(x.device)
+            ms = ev[0].elapsed_time(ev[1])
+            if ms > 0:
+                bw = per / (ms * 1e-3) / 1e9          # bytes to ONE peer / time of the whole exchange (links run in parallel)
+        self.__dict__["_ep_bw"] = bw
+        return bw
+
+
+def _ep_chunks(n_send: int, n_recv: int, M: int = 0, ep: int = 1, bw_gbs: float = 0.0) -> int:
+    """Chunks the expert-parallel exchange is pipelined in (MOE_EP_CHUNKS overrides; 1 = one exchange each way).
+    Chunking costs ~0.1 ms per extra chunk in launch tails (measured) and hides wire time: it is worth it when
+    the bytes to one peer take longer than that on the measured per-peer bandwidth, and a chunk still holds >= 4096
+    rows (a few rounds of 256-row tiles).  With no measurement (bw_gbs == 0) the round-1 rule stands: 4 chunks from
+    16 384 rows."""
     env = os.environ.get("MOE_EP_CHUNKS")
     if env:
         return max(1, int(env))
-    return 4 if min(n_send, n_recv) >= 16384 else 1
-
-
-def _expert_parallel_chunked(self, x, r, act, w1, b1, w2, b2, kept_h, me, C):
-    """Forward-only exchange in C chunks so that the all-to-all of chunk c+1 (and the return of chunk c-1) run on
-    RCCL's stream while the grouped FFN of chunk c runs on the compute stream.  xGMI gives one ~50-60 GB/s link per
-    peer, so at the bench's shapes an unpipelined exchange costs about as much as the FFN itself.
-
-    Chunk c takes rows [c*k/C, (c+1)*k/C) of every (source rank, expert) pair's k kept rows, so both sides derive
-    every split size from the one [ep, E] count matrix.  The send buffer is built chunk-major in one gather launch
-    (through a reordered copy of the dispatch index); the returned rows are put back in compact order by one more."""
-    ep, El = self.ep_size, self.num_local_experts
-    E = ep * El
-    M = x.shape[1]
-    dev = x.device
-    k = kept_h.numpy().astype(np.int64)                                  # [src, e]
-    edges = (k[:, :, None] * np.arange(C + 1, dtype=np.int64)) // C      # [src, e, C+1]
-    cnt = edges[:, :, 1:] - edges[:, :, :-1]                             # [src, e, c]
-    my_off = np.concatenate([[0], np.cumsum(k[me])])                     # compact offsets of my rows per expert
-    order = np.concatenate([np.arange(my_off[e] + edges[me, e, c], my_off[e] + edges[me, e, c + 1])
-                            for c in range(C) for e in range(E)] + [np.zeros(0, dtype=np.int64)])
-    n_send = int(order.size)
-    inv = np.empty(max(n_send, 1), dtype=np.int32)
-    inv[order] = np.arange(n_send, dtype=np.int32)
-    order_d = torch.from_numpy(order.astype(np.int64)).to(dev, non_blocking=True)
-    inv_d = torch.from_numpy(inv).to(dev, non_blocking=True)
-    send_cnt = cnt[me].reshape(ep, El, C).sum(1)                         # [dest, c]
-    recv_cnt = cnt[:, me * El:(me + 1) * El, :]                          # [src, le, c]
-    n_total_dev = r.expert_offsets[E:E + 1]
-    perm_c = r.perm[:n_send][order_d] if n_send else r.perm[:0]          # dispatch index in chunk-major order
-    send = ops.gather_rows(x, perm_c.contiguous(), r.top_k - 1, n_total_dev, n_send)
-    # all chunks' group offsets in one host->device copy: [C, ep*El + 1]
-    offs_h = np.zeros((C, ep * El + 1), dtype=np.int32)
-    offs_h[:, 1:] = np.cumsum(recv_cnt.reshape(ep * El, C).T, axis=1)
-    offs_d = torch.from_numpy(offs_h).to(dev, non_blocking=True)
-    send_edges = np.concatenate([[0], np.cumsum(send_cnt.sum(0))])       # chunk boundaries in the send buffer
-    recvs, works = [], []
-    for c in range(C):
-        n_rc = int(offs_h[c, -1])
-        rc = torch.empty((max(n_rc, 1), M), dtype=x.dtype, device=dev)
-        w = _all_to_all_rows_async(rc[:n_rc], send[send_edges[c]:send_edges[c + 1]], recv_cnt[:, :, c].sum(1).tolist(),
-                                   send_cnt[:, c].tolist(), self.ep_group)
-        recvs.append((rc, n_rc))
-        works.append(w)
-    y_cm = torch.empty((max(n_send, 1), M), dtype=x.dtype, device=dev)   # returned rows, chunk-major
-    back, keep = [], []
-    # The chunks' grouped FFNs alternate between the compute stream and a side stream: a chunk launch is only a few
-    # rounds of 256-row tiles (fc2: 1.4 rounds at the bench's shapes), and with two streams the next chunk's blocks
-    # fill the CUs that the tail of the previous launch leaves idle.
-    cur = torch.cuda.current_stream(dev) if x.is_cuda else None
-    two = cur is not None and C > 1 and os.environ.get("MOE_EP_STREAMS", "2") != "1"
-    if two:
-        side = self.__dict__.get("_side_stream")
-        if side is None or side.device != dev:
-            side = torch.cuda.Stream(device=dev)
-            self.__dict__["_side_stream"] = side
-        side.wait_stream(cur)                                  # the send buffer and the offsets are ready
-    for c in range(C):
-        rc, n_rc = recvs[c]
-        on_side = two and (c & 1)
-        with (torch.cuda.stream(side) if on_side else ops._NULL):
-            with (ops.stream_scope(rc) if two else ops._NULL):  # the launches follow the stream switch
-                if works[c] is not None:
-                    works[c].wait()
-                y_rc = ops.expert_ffn(act, rc, None, 0, w1, b1, w2, b2, offs_d[c], n_rc, timer=self.timer,
-                                      n_gated=self.experts.n_gated)
-                keep.append(y_rc)
-                back.append(_all_to_all_rows_async(y_cm[send_edges[c]:send_edges[c + 1]], y_rc[:n_rc],
-                                                   send_cnt[:, c].tolist(), recv_cnt[:, :, c].sum(1).tolist(),
-                                                   self.ep_group))
-    if two:
-        cur.wait_stream(side)
-    for w in back:
-        if w is not None:
-            w.wait()
-    self.last_ffn_launches = C
-    y = ops.gather_rows(y_cm, inv_d, 0, n_total_dev, n_send)            # back to compact (expert-major) order
-    if y.shape[0] < max(r.max_rows, 1):
-        y = torch.cat([y, y.new_empty((max(r.max_rows, 1) - y.shape[0], M))], 0)
-    return y
-
-
-MOELayer._expert_parallel_chunked = _expert_parallel_chunked
+    rows = min(n_send, n_recv)
+    if bw_gbs <= 0.0:
+        return 4 if rows >= 16384 else 1
+    wire_ms = (n_send * M * 2.0 / max(ep, 1)) / (bw_gbs * 1e9) * 1e3        # one direction, one peer link
+    if rows < 8192 or wire_ms < 0.15:
+        return 1
+    return int(max(2, min(4, rows // 4096, round(wire_ms / 0.15))))
 
 
 class _MoEBlockFn(torch.autograd.Function):

@@ -42,10 +42,36 @@ def _install_cpu_stand_ins():
         dst[:n] = src[(gather[:n] >> shift).long()]
         return dst
 
-    def expert_ffn(act, a, gather, shift, w1, b1, w2, b2, group_offsets, max_rows, timer=None, n_gated=-1):
+    def chunk_pos(offs, C):
+        """chunk-major position of every compact row (host restatement of chunk_rows_kernel's map)."""
+        offs = offs.tolist()
+        E = len(offs) - 1
+        k = [offs[e + 1] - offs[e] for e in range(E)]
+        pos = torch.zeros(max(offs[-1], 1), dtype=torch.long)
+        nxt = 0
+        for c in range(C):
+            for e in range(E):
+                lo, hi = k[e] * c // C, k[e] * (c + 1) // C
+                for i in range(lo, hi):
+                    pos[offs[e] + i] = nxt
+                    nxt += 1
+        return pos[: offs[-1]]
+
+    def ep_chunk_rows(src, gather, shift, expert_offsets, n_chunks, unpack, max_rows, out=None):
+        n = int(expert_offsets[-1])
+        pos = chunk_pos(expert_offsets, n_chunks)
+        if out is None:
+            out = torch.zeros(max(max_rows, 1), src.shape[1], dtype=src.dtype)
+        if unpack:
+            out[:n] = src[pos]
+        else:
+            out[pos] = src[(gather[:n] >> shift).long()] if gather is not None else src[:n]
+        return out
+
+    def expert_ffn(act, a, gather, shift, w1, b1, w2, b2, group_offsets, max_rows, timer=None, n_gated=-1, out=None):
         M = a.shape[1]
         n_local, _, I = w2.shape
-        y = torch.zeros(max(max_rows, 1), M, dtype=torch.bfloat16)
+        y = out[0] if out is not None else torch.zeros(max(max_rows, 1), M, dtype=torch.bfloat16)
         offs = group_offsets.tolist()
         for g in range(len(offs) - 1):
             lo, hi = offs[g], offs[g + 1]
@@ -81,13 +107,16 @@ def _install_cpu_stand_ins():
             h = gelu_new(ab)
         return ab, h, F.linear(h, w2e, b2e)
 
-    def expert_ffn_train(act, a, gather, shift, w1, b1, w2, b2, group_offsets, max_rows, n_gated=-1):
+    def expert_ffn_train(act, a, gather, shift, w1, b1, w2, b2, group_offsets, max_rows, n_gated=-1, out=None):
         M = a.shape[1]
         n_local, _, I = w2.shape
         rows_n = max(max_rows, 1)
-        y = torch.zeros(rows_n, M, dtype=torch.bfloat16)
-        ab = torch.zeros(rows_n, w1.shape[1], dtype=torch.bfloat16)
-        h = torch.zeros(rows_n, I, dtype=torch.bfloat16)
+        if out is not None:
+            y, ab, h = out
+        else:
+            y = torch.zeros(rows_n, M, dtype=torch.bfloat16)
+            ab = torch.zeros(rows_n, w1.shape[1], dtype=torch.bfloat16)
+            h = torch.zeros(rows_n, I, dtype=torch.bfloat16)
         offs = group_offsets.tolist()
         for g in range(len(offs) - 1):
             lo, hi = offs[g], offs[g + 1]
@@ -175,6 +204,7 @@ def _install_cpu_stand_ins():
         return dx.to(torch.bfloat16)
 
     ops.gate_logits, ops.routing_top2, ops.gather_rows = gate_logits, routing_top2, gather_rows
+    ops.ep_chunk_rows = ep_chunk_rows
     ops.expert_ffn, ops.combine = expert_ffn, combine
     def block_top2(x, wg, cap, noise, seed, drop, act, w1, b1, w2, b2, n_gated=-1):
         lg = gate_logits(x, wg)
@@ -333,6 +363,31 @@ def run(rank: int, world: int, port: int, mode: str, kind: str, result_dir: str)
         else:
             assert torch.allclose(dx_p.float(), dx_f.float(), rtol=2e-2, atol=2e-3)
         assert torch.allclose(dwg_p.float(), dwg_f.float(), rtol=1e-4, atol=1e-5)
+        # ---- the same training step with the exchange pipelined in 2 chunks (forward and both backward exchanges):
+        #      rows are the same rows, only their order in the receive buffer changes (chunk, source, expert) ----
+        os.environ["MOE_EP_CHUNKS"] = "2"
+        try:
+            part.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_(True)
+            o2, la2, _ = part(xg)
+            assert part.deepspeed_moe.last_ffn_launches == 2
+            torch.autograd.backward([o2, la2], [R, torch.tensor(0.25, device=dev)])
+        finally:
+            del os.environ["MOE_EP_CHUNKS"]
+        if mode == "gpu":
+            torch.cuda.synchronize()
+            assert torch.equal(o2, want) and torch.equal(xg.grad, dx_p)
+        else:
+            assert torch.allclose(xg.grad.float(), dx_p.float(), rtol=2e-2, atol=2e-3)
+        chunked_grads = {n: p.grad.detach().float().cpu().clone() for n, p in part.deepspeed_moe.experts.named_parameters()}
+        part.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        o, la, _ = part(xg)
+        torch.autograd.backward([o, la], [R, torch.tensor(0.25, device=dev)])
+        for n, p in part.deepspeed_moe.experts.named_parameters():
+            g1 = p.grad.detach().float().cpu()
+            sc = float(g1.abs().max())
+            assert float((chunked_grads[n] - g1).abs().max()) <= 1e-2 * sc + 1e-6, n   # another summation order over rows
         # an expert's weight gradient sums over the tokens of BOTH ranks: all-reduce the ep=1 model's gradients
         fe = full.deepspeed_moe.experts.deepspeed_experts
         for le, mod in enumerate(part.deepspeed_moe.experts.deepspeed_experts):

@@ -36,7 +36,18 @@ def timeit(label):
         for _ in range(20):
             moe(x)
         torch.cuda.synchronize()
-    print(f"{label:40s} {(time.perf_counter() - t0) / 20 * 1e3:7.3f} ms/step", flush=True)
+    step = (time.perf_counter() - t0) / 20
+    # host time of one call: how long the Python call takes to RETURN with an idle GPU queue (launches are asynchronous;
+    # the expert-parallel path additionally waits for the kept-count matrix, its one host sync)
+    host = []
+    with torch.no_grad():
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            moe(x)
+            host.append(time.perf_counter() - t1)
+            torch.cuda.synchronize()
+    print(f"{label:40s} {step * 1e3:7.3f} ms/step   host time per call {sorted(host)[len(host) // 2] * 1e6:7.1f} us", flush=True)
 
 
 timeit("local path (ep_size 1, no exchange)")
