@@ -399,51 +399,64 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             stage(0, 0);
         }
         if (EPI == EPI_SWIGLU) {
-            // whole tile gated (plain SwiGLU, or a RePaMLP tile below the mask boundary): no per-element select
+            // whole tile gated (plain SwiGLU, or a RePaMLP tile below the mask boundary): no per-element select.  Bias and
+            // mask are block-uniform, so the loop is instantiated per (bias, all gated) combination: with run-time tests
+            // inside it the compiler kept 4 packed adds + 8 selects per 4 outputs in the bias-free path too.
             const bool all_gated = ct * NC + NC <= p.n_gated;  // uniform per block
+            auto swiglu_epi = [&](auto has_bias_c, auto all_gated_c) {
+                constexpr bool HAS_BIAS = decltype(has_bias_c)::value != 0;
+                constexpr bool ALL_GATED = decltype(all_gated_c)::value != 0;
 #pragma unroll
-            for (int nf = 0; nf < NF / 2; ++nf) {
-                const int cl = wn * (WNT / 2) + nf * 16 + fq * 4;  // column inside the tile
-                const int c0 = ct * NC + cl;
-                float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
-                if (bias && c0 < p.N_out) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ba[j] = E::to_f(bias[c0 + j]);
-                        bb[j] = E::to_f(bias[p.b_row_offset + c0 + j]);
-                    }
-                }
-#pragma unroll
-                for (int mf = 0; mf < MFW; ++mf) {
-                    // the reference's rounding points: bf16 outputs of the two Linears, bf16 F.silu, bf16 product;
-                    // roundings go two at a time through v_cvt_pk_bf16_f32
-                    float a[4], b[4], sg[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        a[j] = acc[nf][mf][j];
-                        b[j] = acc[nf + NF / 2][mf][j];
-                    }
-                    if (bias) {
+                for (int nf = 0; nf < NF / 2; ++nf) {
+                    const int cl = wn * (WNT / 2) + nf * 16 + fq * 4;  // column inside the tile
+                    const int c0 = ct * NC + cl;
+                    float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (HAS_BIAS && c0 < p.N_out) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            a[j] += ba[j];
-                            b[j] += bb[j];
+                            ba[j] = E::to_f(bias[c0 + j]);
+                            bb[j] = E::to_f(bias[p.b_row_offset + c0 + j]);
                         }
                     }
-                    round2<DT>(a[0], a[1]); round2<DT>(a[2], a[3]); round2<DT>(b[0], b[1]); round2<DT>(b[2], b[3]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sg[j] = fast_silu(a[j]);
-                    round2<DT>(sg[0], sg[1]); round2<DT>(sg[2], sg[3]);
-                    if (!all_gated) {
-                        // RePaMLP: torch.where(mask, silu, 1) (llava_stablelm_moe.py:636-638)
+                    for (int mf = 0; mf < MFW; ++mf) {
+                        // the reference's rounding points: 16-bit outputs of the two Linears, 16-bit F.silu, 16-bit product;
+                        // roundings go two at a time through one packed convert
+                        float a[4], b[4], sg[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) sg[j] = (c0 + j < p.n_gated) ? sg[j] : 1.0f;
+                        for (int j = 0; j < 4; ++j) {
+                            a[j] = acc[nf][mf][j];
+                            b[j] = acc[nf + NF / 2][mf][j];
+                        }
+                        if (HAS_BIAS) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                a[j] += ba[j];
+                                b[j] += bb[j];
+                            }
+                        }
+                        round2<DT>(a[0], a[1]); round2<DT>(a[2], a[3]); round2<DT>(b[0], b[1]); round2<DT>(b[2], b[3]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sg[j] = fast_silu(a[j]);
+                        round2<DT>(sg[0], sg[1]); round2<DT>(sg[2], sg[3]);
+                        if (!ALL_GATED) {
+                            // RePaMLP: torch.where(mask, silu, 1) (llava_stablelm_moe.py:636-638)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) sg[j] = (c0 + j < p.n_gated) ? sg[j] : 1.0f;
+                        }
+                        uint2 o;
+                        o.x = E::pack2(sg[0] * b[0], sg[1] * b[1]);
+                        o.y = E::pack2(sg[2] * b[2], sg[3] * b[3]);
+                        *reinterpret_cast<uint2 *>(img + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
                     }
-                    uint2 o;
-                    o.x = E::pack2(sg[0] * b[0], sg[1] * b[1]);
-                    o.y = E::pack2(sg[2] * b[2], sg[3] * b[3]);
-                    *reinterpret_cast<uint2 *>(img + (row_off + mf * 16 + fr) * ROWB + cl * 2) = o;
                 }
+            };
+            if (bias) {
+                if (all_gated) swiglu_epi(IntC<1>{}, IntC<1>{});
+                else swiglu_epi(IntC<1>{}, IntC<0>{});
+            } else {
+                if (all_gated) swiglu_epi(IntC<0>{}, IntC<1>{});
+                else swiglu_epi(IntC<0>{}, IntC<0>{});
             }
         } else {
 #pragma unroll
