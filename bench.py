@@ -373,21 +373,25 @@ def main():
     # the workload differs from the profiled one.
     if roofline is not None and world == 1 and default_run:
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary_*.json")))
-        if cands:
-            pmc = cands[-1]                                  # newest committed summary
+        # newest committed summary of THIS config (file name "..._cfg<N>.json") that holds the fc1 kernel
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_summary_*cfg{args.config}.json")),
+                       key=lambda f: (os.path.basename(os.path.dirname(f)), os.path.basename(f)), reverse=True)
+
+        def is_fc1(name):                                    # grouped_gemm_kernel<DT, EPI, BM, BNW>: bf16 SwiGLU 256 x 256
+            if "grouped_gemm_kernel<" not in name:
+                return False
+            targs = [t.strip() for t in name.split("<", 1)[1].split(">", 1)[0].split(",")]
+            return targs[-3:] == ["1", "256", "256"] and (len(targs) == 3 or targs[0] == "0")
+        for pmc in cands:
             summary = json.load(open(pmc))
-            def is_fc1(name):                                # grouped_gemm_kernel<[DT,] EPI, BM, BNW>: SwiGLU 256 x 256
-                if "grouped_gemm_kernel<" not in name:
-                    return False
-                targs = [t.strip() for t in name.split("<", 1)[1].split(">", 1)[0].split(",")]
-                return targs[-3:] == ["1", "256", "256"] and (len(targs) == 3 or targs[0] == "0")
-            k = next((v for name, v in summary.items() if is_fc1(name) and "hbm_bytes_per_launch" in v), {})
-            if "hbm_bytes_per_launch" in k:
-                roofline["traffic"] = k["hbm_bytes_per_launch"]
-                roofline["traffic_unit"] = ("bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, "
-                                            + os.path.relpath(pmc, ROOT) + ")")
-                roofline["algorithmic_bytes"] = 2.0 * (2 * I * M * E) + 2.0 * S * M + 2.0 * rows_local * I
+            k = next((v for name, v in summary.items() if is_fc1(name) and "hbm_bytes_per_launch" in v), None)
+            if k is None:
+                continue
+            roofline["traffic"] = k["hbm_bytes_per_launch"]
+            roofline["traffic_unit"] = ("bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, "
+                                        + os.path.relpath(pmc, ROOT) + ")")
+            roofline["algorithmic_bytes"] = 2.0 * (2 * I * M * E) + 2.0 * S * M + 2.0 * rows_local * I
+            break
     # ---- informational: one training step (forward + backward through the autograd node) on the same batch; not part
     #      of `value` (BASELINE's metric is the forward block) ----
     training = None

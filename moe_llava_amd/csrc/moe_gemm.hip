@@ -42,6 +42,17 @@ constexpr int NTHREADS = 512;
 #ifndef GEMM_ASYM_MF
 #define GEMM_ASYM_MF 5  // row fragments (of 16) of a loader wave; its partner owns 16 - this
 #endif
+#ifndef GEMM_OVERLAP_SMALL
+#define GEMM_OVERLAP_SMALL 0  // 1: persistent launches with the output image behind ring slot 0 for the 128 / 64-row tiles too
+                              // (measured -2 % on config 1's fc1, nothing elsewhere: a fill-rate-bound tile has no idle
+                              // fill time to move its prologue into; off, so that small launches stay one block per tile)
+#endif
+#ifndef GEMM_ASYM_MF128
+#define GEMM_ASYM_MF128 3  // 128-row tiles: loader wave's share of the 8 row fragments (4 = symmetric)
+#endif
+#ifndef GEMM_ASYM_MF64
+#define GEMM_ASYM_MF64 1   // 64-row tiles: loader wave's share of the 4 row fragments (2 = symmetric)
+#endif
 #ifndef GEMM_PERSIST
 #define GEMM_PERSIST 1  // 256 x 256 launches of more than 256 tiles run as 256 persistent blocks (one per CU)
 #endif
@@ -78,7 +89,9 @@ struct Tile {
     static constexpr int NC = (EPI == EPI_SWIGLU) ? BNW / 2 : BNW;  // output columns per tile
     static constexpr int ROWB = NC * 2 + EPI_PAD;                   // bytes per image row
     // persistent SwiGLU launches of the big tile put the output image behind ring slot 0 (see the kernel)
-    static constexpr bool OVERLAP = GEMM_PERSIST && EPI == EPI_SWIGLU && BM == 256 && BNW == 256;
+    // (the big tile's plain / gelu image, 132 KiB, does not fit behind a 64 KiB slot; every smaller tile's does)
+    static constexpr bool OVERLAP = GEMM_PERSIST && GEMM_OVERLAP_SMALL >= (BM < 256 ? 1 : 0) &&
+                                    (BM == 256 ? (EPI == EPI_SWIGLU && BNW == 256) : (BM >= 64 && SLOT_BYTES + BM * ROWB <= 147456));
     static constexpr int IMG_BYTES = (OVERLAP ? SLOT_BYTES : 0) + BM * ROWB;
     static constexpr int LDS_BYTES = NS * SLOT_BYTES > IMG_BYTES ? NS * SLOT_BYTES : IMG_BYTES;
     static constexpr int MF = BM / 32;   // 16-row fragments per wave (wave tile BM/2 rows)
@@ -90,6 +103,9 @@ struct Tile {
 // Diagnostic build only (cdna guide section 7, in-kernel stamps): per-wave cycle sums of the K-loop segments go to a
 // buffer of their own, never to an output.
 __device__ unsigned long long g_stamps[8 * 8 * 8];
+#ifndef GEMM_STAMP_BASE
+#define GEMM_STAMP_BASE 1024  // first of the 8 stamped blocks
+#endif
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -279,9 +295,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         // K loop: ring of NS slots, NS-1 K slices of LDS-DMA in flight behind the one being consumed, one counted
         // vmcnt + raw s_barrier per slice.  At step kt the slices issued behind kt are min(NS-2, nk-1-kt), PP LDS-DMA
         // instructions per loader wave each.
+        // (a persistent launch staged this tile's slice 0 under the previous tile's epilogue; deeper rings fill their other
+        // slots once every wave has read the previous tile's image out of them)
+        if (OVERLAP && NS > 2 && staged) __syncthreads();
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s)
-            if (LOADS && !staged && s < nk) stage(s, s);
+            if (LOADS && !(staged && s == 0) && s < nk) stage(s, s);
 #ifdef GEMM_STAMPS
         st_t0 = stamp(); st_begin = st_t0;
 #endif
@@ -493,7 +512,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     // code, so the staging pointers are dead there and 176 accumulator registers fit (244 VGPRs, no spill).  Same
     // MFMA operands per output element: bit-identical.  Measured (same-process A/B, config 2): fc2 862 -> 814 us
     // (+5.9 %), fc1 1622 -> 1593 us (+1.8 %); splits 4/12, 6/10, 7/9 are within 1.5 % of 5/11.
-    constexpr bool ASYM = GEMM_ASYM && BM == 256 && BNW == 256 && LW == 4;
+    // The smaller row tiles (weight-streaming regime) split the same way: their K step was issue (one 1-KiB piece per
+    // ~65 cycles: the 64 B/clk of the vector L1) + the loader's MFMAs in series, 1800 cycles against 1024 of matrix-pipe
+    // work per SIMD (in-kernel stamps, config 1's fc1).
+    constexpr int TF = BM / 16;  // row fragments of the tile
+    constexpr int AMF = BM == 256 ? GEMM_ASYM_MF : BM == 128 ? GEMM_ASYM_MF128 : BM == 64 ? GEMM_ASYM_MF64 : TF / 2;
+    constexpr bool ASYM = GEMM_ASYM && LW == 4 && (BM == 256 ? BNW == 256 : AMF != TF / 2);
     // The tile loop (one pass for one-tile-per-block launches), instantiated per wave role so that the staging pointers
     // are dead in the partner waves' whole loop.
     auto run_tiles = [&](auto mfw_c, auto loads_c, const int row_off) {
@@ -557,8 +581,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         }
     };
     if (ASYM) {
-        if (__builtin_amdgcn_readfirstlane(wave) < 4) run_tiles(IntC<GEMM_ASYM_MF>{}, IntC<1>{}, 0);
-        else run_tiles(IntC<16 - GEMM_ASYM_MF>{}, IntC<0>{}, GEMM_ASYM_MF * 16);
+        if (__builtin_amdgcn_readfirstlane(wave) < 4) run_tiles(IntC<AMF>{}, IntC<1>{}, 0);
+        else run_tiles(IntC<TF - AMF>{}, IntC<0>{}, AMF * 16);
     } else {
         run_tiles(IntC<MF>{}, IntC<1>{}, wm * (BM / 2));
     }
@@ -566,8 +590,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #ifdef GEMM_STAMPS
     {
         const unsigned long long st_end = stamp();
-        if (lane == 0 && blockIdx.x >= 1024 && blockIdx.x < 1032) {
-            unsigned long long *o = g_stamps + ((blockIdx.x - 1024) * 8 + wave) * 8;
+        if (lane == 0 && blockIdx.x >= GEMM_STAMP_BASE && blockIdx.x < GEMM_STAMP_BASE + 8) {
+            unsigned long long *o = g_stamps + ((blockIdx.x - GEMM_STAMP_BASE) * 8 + wave) * 8;
             o[0] = st_wait; o[1] = st_issue; o[2] = st_comp; o[3] = st_loop_end - st_begin; o[4] = st_end - st_loop_end;
             o[5] = nk; o[6] = st_begin - st_entry; o[7] = st_end;
         }
@@ -628,7 +652,10 @@ static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     // SwiGLU the next tile's first fills overlap the epilogue); MOE_NO_PERSIST=1 keeps one block per tile
     // (measured: fc1 of config 2, 7832 tiles, -1.3 %; launches of a few rounds gain nothing and, being 256 resident
     // blocks, could no longer interleave with a second stream's launch, so they keep one block per tile)
+    // Small row tiles, -DGEMM_OVERLAP_SMALL=1 builds only: launches of more than one round run persistent too, with the
+    // next tile's pointers and first slice under the epilogue.
     if (GEMM_PERSIST && BM == 256 && BNW == 256 && grid >= 4096 && !getenv("MOE_NO_PERSIST")) grid = 256;
+    if (BM < 256 && Tile<EPI, BM, BNW>::OVERLAP && grid > 256 && !getenv("MOE_NO_PERSIST")) grid = 256;
     hipLaunchKernelGGL((grouped_gemm_kernel<DT, EPI, BM, BNW>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, p);
     return check_launch("grouped_gemm_kernel");
 }

@@ -5,8 +5,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VAR = os.environ.get("STAMPS_VARIANT", "stamps")
-os.environ["MOE_NO_PERSIST"] = "1"   # the stamped blocks are virtual blocks 1024..1031 of a one-tile-per-block launch
-sys.argv = [sys.argv[0], "--rounds", "1", "--iters", "1", "--shape", sys.argv[1] if len(sys.argv) > 1 else "fc2", VAR]
+os.environ["MOE_NO_PERSIST"] = "1"   # the stamped blocks are virtual blocks GEMM_STAMP_BASE..+7 (1024) of a one-tile-per-block launch
+# usage: stamps.py [fc1|fc2] [extra gemm_bench.py arguments, e.g. --rows 1408 --cold 12]
+sys.argv = [sys.argv[0], "--rounds", "1", "--iters", "1", "--shape", sys.argv[1] if len(sys.argv) > 1 else "fc2", *sys.argv[2:], VAR]
 exec(open(os.path.join(ROOT, "tools", "gemm_bench.py")).read())
 lib = libs[VAR]
 buf = (ctypes.c_ulonglong * 512)()

@@ -19,6 +19,8 @@ VARIANTS = [("auto", None)] + [(f"{bm},{bnw}", f"{bm},{bnw}") for bm in (32, 64,
 if os.environ.get("SWEEP_ORDER"):   # A/B of the tile order (MOE_GEMM_ORDER: 0 = super-rows, 1 = group-major) on a few tiles
     VARIANTS = [(f"{t or 'auto'} order={o}", t, o) for t in (None, "128,256", "128,128", "256,256", "64,256", "256,128")
                 for o in ("0", "1")]
+elif os.environ.get("SWEEP_AUTO"):    # only the library's own choice (A/B of library builds through MOE_GFX950_LIB)
+    VARIANTS = [("auto", None, None)]
 else:
     VARIANTS = [(a, b, None) for a, b in VARIANTS]
 N_LAYERS = int(os.environ.get("SWEEP_LAYERS", "5"))
