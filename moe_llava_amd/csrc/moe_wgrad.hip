@@ -29,6 +29,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #ifndef WG_ASYM_MF
 #define WG_ASYM_MF 4   // rows fragments of a loader wave (4 / 12 measured 2.7 % faster than 5 / 11 here: the loader chain is the critical one)
 #endif
+#ifndef WG_PD
+#define WG_PD 2        // A fragments read ahead of the MFMAs
+#endif
+#ifndef WG_XB_FLY
+#define WG_XB_FLY 0    // 1: A-fragment LDS offsets recomputed per read (3 VALU) instead of MFW registers held over the loop
+#endif
 template <int N>
 struct WIntC { static constexpr int value = N; };
 constexpr int WT = 256;   // tile edge (both output dims)
@@ -51,12 +57,31 @@ struct WgradParams {
     int r_tiles, n_tiles;
 };
 
-__device__ __forceinline__ void glds16w(const bf16_t *gsrc, bf16_t *lds_wave_base) {
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB at lds_wave_base), source = uniform base + 32-bit lane offset.
+// Issued from inline asm on purpose.  After the builtin form (__builtin_amdgcn_global_load_lds) the compiler's waitcnt
+// pass puts an s_waitcnt vmcnt(0) in front of the next ds_read_b64_tr_b16 INTRINSIC (it does not for plain
+// ds_read_b128 loads, which is why moe_gemm.hip is not affected): every loader wave then waited for the slice it had
+// just requested before reading the fragments of the current one -- fill and MFMA in series, 3750 cycles per K slice
+// (in-kernel stamps) instead of max(fill, MFMA).  The asm form is invisible to that pass; the landing of the pieces is
+// waited for explicitly (wait_vm_barrier_w), as before.  M0 (the LDS base of the DMA) is saved and restored.
+#ifndef WG_DMA_ASM
+#define WG_DMA_ASM 1
+#endif
+__device__ __forceinline__ void glds16w(const char *base_uniform, unsigned lane_off, bf16_t *lds_wave_base) {
+#if WG_DMA_ASM
+    const unsigned la = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_wave_base)));
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "s"(la), "v"(lane_off), "s"(base_uniform)
+                 : "memory");
+#else
     __builtin_amdgcn_global_load_lds(
-        reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(gsrc)),
+        reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(base_uniform + lane_off)),
         reinterpret_cast<__attribute__((address_space(3))) void *>(
             static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_wave_base))),
         16, 0, 0);
+#endif
 }
 
 template <int N>
@@ -67,8 +92,27 @@ __device__ __forceinline__ void wait_vm_barrier_w() {
 // chunk swizzle key of k row k (16-byte chunks, even values keep the two chunks of a 32-byte run adjacent)
 __device__ __forceinline__ int ksw(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
 
+#ifdef WG_STAMPS
+// Diagnostic build only: per-wave cycle sums of the K-loop segments of 8 blocks, in a buffer of their own.
+#ifndef WG_STAMP_BASE
+#define WG_STAMP_BASE 300
+#endif
+__device__ unsigned long long g_wstamps[8 * 8 * 8];
+__device__ __forceinline__ unsigned long long wstamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
+
 __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams p) {
     __shared__ __attribute__((aligned(16))) char lds[W_LDS_BYTES];
+#ifdef WG_STAMPS
+    unsigned long long st_wait = 0, st_issue = 0, st_comp = 0, st_steps = 0;
+    const unsigned long long st_entry = wstamp();
+#endif
 
     // ---- block -> (expert, r tile, n tile): XCD-contiguous chunks ----
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -141,10 +185,18 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
         for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
             for (int mf = 0; mf < MFW; ++mf) acc[nf][mf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // LDS offset of A fragment mf: the chunk XOR makes it non-affine in mf; held in MFW registers or rebuilt per read
+        const int xrow = (fq * 8 + tq) * (WT * 2) + ((tp & 1) << 3);
+        const int xc0 = (row_off >> 3) + (tp >> 1);
+#if WG_XB_FLY
+        int keyv = key;  // re-materialised per K slice (see the loop): keeps the compiler from hoisting all MFW offsets back into registers
+        auto xoff = [&](int mf) { return xrow + (((xc0 + mf * 2) ^ keyv) << 4); };
+#else
         int xb[MFW];
 #pragma unroll
-        for (int mf = 0; mf < MFW; ++mf)
-            xb[mf] = (fq * 8 + tq) * (WT * 2) + ((((row_off >> 3) + mf * 2 + (tp >> 1)) ^ key) << 4) + ((tp & 1) << 3);
+        for (int mf = 0; mf < MFW; ++mf) xb[mf] = xrow + (((xc0 + mf * 2) ^ key) << 4);
+        auto xoff = [&](int mf) { return xb[mf]; };
+#endif
         // the groups of this expert: e, e + El, ... ; each is a K range of its own (expert-parallel receive layout)
         const int per = p.G / p.n_experts;
         for (int src = 0; src < per; ++src) {
@@ -167,30 +219,40 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
 #pragma unroll
                     for (int j = 0; j < NPL; ++j) {
                         const int t = (j & 1) | ((((lwave * NPL + j) >> 2) & 1) << 1);
-                        glds16w(reinterpret_cast<const bf16_t *>(abase + (ra + (unsigned)(2 * j) * lda_b + (unsigned)a_col[t])),
-                                slot + j * 512);
-                        glds16w(reinterpret_cast<const bf16_t *>(bbase + (rb + (unsigned)(2 * j) * ldb_b + (unsigned)b_col[t])),
-                                slot + WBK * WT + j * 512);
+                        glds16w(abase, ra + (unsigned)(2 * j) * lda_b + (unsigned)a_col[t], slot + j * 512);
+                        glds16w(bbase, rb + (unsigned)(2 * j) * ldb_b + (unsigned)b_col[t], slot + WBK * WT + j * 512);
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < NPL; ++j) {
                         const int t = (j & 1) | ((((lwave * NPL + j) >> 2) & 1) << 1);
                         const unsigned r = min(row0 + (unsigned)(2 * j), (unsigned)(nrows - 1));
-                        glds16w(reinterpret_cast<const bf16_t *>(abase + (r * lda_b + (unsigned)a_col[t])), slot + j * 512);
-                        glds16w(reinterpret_cast<const bf16_t *>(bbase + (r * ldb_b + (unsigned)b_col[t])),
-                                slot + WBK * WT + j * 512);
+                        glds16w(abase, r * lda_b + (unsigned)a_col[t], slot + j * 512);
+                        glds16w(bbase, r * ldb_b + (unsigned)b_col[t], slot + WBK * WT + j * 512);
                     }
                 }
             };
             __syncthreads();  // previous group's last slice is fully consumed before the ring is reused
             stage(0, 0);
             for (int kt = 0; kt < nk; ++kt) {
+#ifdef WG_STAMPS
+                const unsigned long long st_t0 = wstamp();
+#endif
                 wait_vm_barrier_w<0>();
+#ifdef WG_STAMPS
+                const unsigned long long st_t1 = wstamp();
+#endif
 #ifndef WG_NO_LOAD
                 if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
 #endif
+#ifdef WG_STAMPS
+                const unsigned long long st_t2 = wstamp();
+#endif
                 const char *lb = lds_b + (kt & 1) * (W_SLOT_ELEMS * 2);
+#if WG_XB_FLY
+                asm volatile("" : "+v"(keyv));
+#endif
+#ifndef WG_NO_ZERO
                 if (kt == nk - 1 && (nrows & (WBK - 1))) {
                     // zero the k rows past the group's end in both tiles (they hold a copy of the last row), then re-sync
                     const int rem = nrows & (WBK - 1);
@@ -202,17 +264,18 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
                     }
                     __syncthreads();
                 }
+#endif
 #ifndef WG_NO_MFMA
 #if WG_PIPE
                 // software-pipelined fragment reads, as in moe_gemm.hip: the 4 B fragments of a k-step stay in registers, the
                 // A fragments stream through a window of 3, the next k-step's B fragments are read under the last MFMAs
                 {
-                    constexpr int PD = 2, TT = 2 * MFW;
+                    constexpr int PD = WG_PD, TT = 2 * MFW;
                     bf16x8_t wf[2][4], xf[TT];
 #pragma unroll
                     for (int nf = 0; nf < 4; ++nf) wf[0][nf] = tr8(lb, wb[nf]);
 #pragma unroll
-                    for (int t = 0; t < PD; ++t) xf[t] = tr8(lb, xb[t % MFW] + (t / MFW) * 32 * WT * 2);
+                    for (int t = 0; t < PD; ++t) xf[t] = tr8(lb, xoff(t % MFW) + (t / MFW) * 32 * WT * 2);
                     __builtin_amdgcn_sched_barrier(0);
 #ifndef WG_NO_SETPRIO
                     __builtin_amdgcn_s_setprio(1);
@@ -220,7 +283,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
 #pragma unroll
                     for (int t = 0; t < TT; ++t) {
                         const int ks = t / MFW, mf = t % MFW;
-                        if (t + PD < TT) xf[t + PD] = tr8(lb, xb[(t + PD) % MFW] + ((t + PD) / MFW) * 32 * WT * 2);
+                        if (t + PD < TT) xf[t + PD] = tr8(lb, xoff((t + PD) % MFW) + ((t + PD) / MFW) * 32 * WT * 2);
                         if (ks == 0 && mf >= MFW - 4) wf[1][mf - (MFW - 4)] = tr8(lb, wb[mf - (MFW - 4)] + 32 * WT * 2);
 #pragma unroll
                         for (int nf = 0; nf < 4; ++nf)
@@ -238,7 +301,7 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
 #pragma unroll
                     for (int nf = 0; nf < 4; ++nf) wf[nf] = tr8(lb, wb[nf] + ks * 32 * WT * 2);
 #pragma unroll
-                    for (int mf = 0; mf < MFW; ++mf) xf[mf] = tr8(lb, xb[mf] + ks * 32 * WT * 2);
+                    for (int mf = 0; mf < MFW; ++mf) xf[mf] = tr8(lb, xoff(mf) + ks * 32 * WT * 2);
 #ifndef WG_NO_SETPRIO
                     __builtin_amdgcn_s_setprio(1);
 #endif
@@ -253,8 +316,18 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
                 }
 #endif
 #endif
+#ifdef WG_STAMPS
+                const unsigned long long st_t3 = wstamp();
+                st_wait += st_t1 - st_t0; st_issue += st_t2 - st_t1; st_comp += st_t3 - st_t2; st_steps += 1;
+#endif
             }
         }
+#ifdef WG_STAMPS
+        if (lane == 0 && blockIdx.x >= WG_STAMP_BASE && blockIdx.x < WG_STAMP_BASE + 8) {
+            unsigned long long *o = g_wstamps + ((blockIdx.x - WG_STAMP_BASE) * 8 + wave) * 8;
+            o[0] = st_wait; o[1] = st_issue; o[2] = st_comp; o[3] = st_steps; o[4] = wstamp() - st_entry;
+        }
+#endif
 
         // ---- epilogue: bf16 tile image in LDS -> 16-byte full-line stores ----
         __syncthreads();
@@ -319,3 +392,9 @@ int launch_wgrad_tn(const bf16_t *a, long long lda, const bf16_t *b, long long l
 }
 
 }  // namespace moe
+
+#ifdef WG_STAMPS
+extern "C" int moe_debug_read_wstamps(unsigned long long *host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(moe::g_wstamps), sizeof(unsigned long long) * 512);
+}
+#endif
