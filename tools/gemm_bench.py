@@ -27,6 +27,7 @@ ap.add_argument("--shape", default="both")
 ap.add_argument("--skew", type=int, default=1)
 ap.add_argument("--sorted", type=int, default=1, help="gather rows in token order (as the routing kernel produces them)")
 ap.add_argument("--cold", type=int, default=1, help="weight copies cycled per call (cold weights for decode-size runs)")
+ap.add_argument("--gelu", type=int, default=0, help="fc1 = Phi form: W1 [E, I, M] + bias, gelu_new epilogue (default: gated SwiGLU, W1 [E, 2I, M])")
 ap.add_argument("--pad", type=int, default=0, help="pad leading dims of x / h (and the w buffers, for -DGEMM_EXP_LDW_PAD builds)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -35,7 +36,9 @@ M, I, E, R = a.M, a.I, a.E, a.rows
 S = R // 2
 P = a.pad
 x = torch.randn(S, M + P, device=dev).to(torch.bfloat16)
-w1s = [(torch.randn(E, 2 * I + 8, M + P, device=dev) * 0.02).to(torch.bfloat16) for _ in range(a.cold)]
+N1 = I if a.gelu else 2 * I
+w1s = [(torch.randn(E, N1 + 8, M + P, device=dev) * 0.02).to(torch.bfloat16) for _ in range(a.cold)]
+b1 = (torch.randn(E, N1 + 8, device=dev) * 0.02).to(torch.bfloat16)
 w2s = [(torch.randn(E, M + 8, I + P, device=dev) * 0.02).to(torch.bfloat16) for _ in range(a.cold)]
 calls = [0, 0]
 if a.skew:
@@ -52,14 +55,17 @@ libs = {v: load(v) for v in a.variants}
 
 def fc1(lib):
     w1 = w1s[calls[0] % a.cold]; calls[0] += 1
-    rc = lib.moe_grouped_gemm_fwd(1, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), None, offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, 0, st)
+    if a.gelu:
+        rc = lib.moe_grouped_gemm_fwd(2, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), b1.data_ptr(), offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, 0, st)
+    else:
+        rc = lib.moe_grouped_gemm_fwd(1, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), None, offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, 0, st)
     assert rc == 0, lib.moe_last_error()
 def fc2(lib):
     w2 = w2s[calls[1] % a.cold]; calls[1] += 1
     rc = lib.moe_grouped_gemm_fwd(0, h.data_ptr(), I + P, None, 0, w2.data_ptr(), None, offs.data_ptr(), E, E, R, I, M, -1, y.data_ptr(), M, 0, st)
     assert rc == 0, lib.moe_last_error()
 
-shapes = {"fc1": (fc1, 2.0 * R * 2 * I * M), "fc2": (fc2, 2.0 * R * M * I)}
+shapes = {"fc1": (fc1, 2.0 * R * N1 * M), "fc2": (fc2, 2.0 * R * M * I)}
 todo = ["fc1", "fc2"] if a.shape == "both" else [a.shape]
 ref = None
 for v, lib in libs.items():
