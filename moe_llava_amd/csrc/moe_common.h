@@ -210,17 +210,23 @@ __device__ __forceinline__ void gelu_new_pair(float &a, float &b) {
 // Backward of the activations on 8 packed elements, with the bf16 rounding points of the autograd graph of the
 // reference's bf16 modules.  SwiGLU: h = silu(a) * b (masked channels: h = b):  db = g * silu(a), d silu = g * b,
 // da = d silu * silu'(a).  gelu_new: dx = g * d/dx[0.5 x (1 + tanh(k (x + 0.044715 x^3)))].
-__device__ __forceinline__ void swiglu_bwd8(const float *a, const float *b, const float *g, int c0, int n_gated, float *da,
-                                            float *db) {
+// ALL_GATED: every one of the 8 columns is below the RePaMLP mask boundary (plain SwiGLU: always) -- no per-element select
+template <bool ALL_GATED>
+__device__ __forceinline__ void swiglu_bwd8_t(const float *a, const float *b, const float *g, int c0, int n_gated, float *da,
+                                              float *db) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const bool gated = c0 + i < n_gated;  // RePaMLP: masked channels are 1 * b, no gradient to a
+        const bool gated = ALL_GATED || c0 + i < n_gated;  // RePaMLP: masked channels are 1 * b, no gradient to a
         const float sig = fast_sigmoid(a[i]);
         const float sg = gated ? rbf(a[i] * sig) : 1.0f;
         db[i] = g[i] * sg;
         const float dsg = rbf(g[i] * b[i]);
         da[i] = gated ? dsg * (sig * (1.f + a[i] * (1.f - sig))) : 0.f;
     }
+}
+__device__ __forceinline__ void swiglu_bwd8(const float *a, const float *b, const float *g, int c0, int n_gated, float *da,
+                                            float *db) {
+    swiglu_bwd8_t<false>(a, b, g, c0, n_gated, da, db);
 }
 __device__ __forceinline__ void gelu_new_bwd8(const float *a, const float *g, float *dx) {
 #pragma unroll

@@ -42,6 +42,9 @@ constexpr int NTHREADS = 512;
 #ifndef GEMM_ASYM_MF
 #define GEMM_ASYM_MF 5  // row fragments (of 16) of a loader wave; its partner owns 16 - this
 #endif
+#ifndef GEMM_BWD_EPI_U
+#define GEMM_BWD_EPI_U 8  // rows per thread whose pre-activation loads are in flight together in the fused activation-backward store phase
+#endif
 #ifndef GEMM_OVERLAP_SMALL
 #define GEMM_OVERLAP_SMALL 0  // 1: persistent launches with the output image behind ring slot 0 for the 128 / 64-row tiles too
                               // (measured -2 % on config 1's fc1, nothing elsewhere: a fill-rate-bound tile has no idle
@@ -535,30 +538,62 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 const int cc = tid % CPR, r0 = tid / CPR;
                 const int col = ct * NC + cc * 8;
                 const int ncols_ok = p.N_out - col;            // > 0 columns valid from here (N_out % 4 == 0)
+                if (EPI == EPI_DSWIGLU || EPI == EPI_DGELU) {
+                    // The image holds dH (bf16, as the standalone path stores it); the store phase turns 8 elements at a time
+                    // into dAB with the kept pre-activations (N_out % 8 == 0 here).  The pre-activation loads of a batch of U
+                    // rows are all issued before the first is used, from clamped (always valid) addresses and outside any
+                    // branch: as one load - use - store chain per row the phase paid 16 global-load latencies per tile and
+                    // was as long as the K loop (fc2 data gradient 1237 us against 800 us for the plain launch).
+                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                    constexpr int PASSES = (BM + ROWS_PER_IT - 1) / ROWS_PER_IT;
+                    constexpr int U = PASSES < GEMM_BWD_EPI_U ? PASSES : GEMM_BWD_EPI_U;
+                    const int colc = min(col, p.N_out - 8);
+                    auto bwd_store = [&](auto all_gated_c) {
+                        constexpr bool ALL_GATED = decltype(all_gated_c)::value != 0;
+                        for (int rb = r0; rb < BM; rb += ROWS_PER_IT * U) {
+                            u32x4_t va[U], vb2[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const int prow = min(row_begin + rb + u * ROWS_PER_IT, row_end - 1);
+                                const bf16_t *abrow = p.aux + (long long)prow * p.ld_aux + colc;
+                                va[u] = *reinterpret_cast<const u32x4_t *>(abrow);
+                                if (EPI == EPI_DSWIGLU) vb2[u] = *reinterpret_cast<const u32x4_t *>(abrow + p.b_row_offset);
+                            }
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const int r = rb + u * ROWS_PER_IT;
+                                const int prow = row_begin + r;
+                                if (r < BM && prow < row_end && ncols_ok > 0) {
+                                    const uint4 v = *reinterpret_cast<const uint4 *>(img + r * ROWB + cc * 16);
+                                    bf16_t *dst = p.out + (long long)prow * p.ldo + col;
+                                    float g[8], a[8];
+                                    unpack8(v, g);
+                                    unpack8(make_uint4(va[u][0], va[u][1], va[u][2], va[u][3]), a);
+                                    if (EPI == EPI_DSWIGLU) {
+                                        float b[8], da[8], db[8];
+                                        unpack8(make_uint4(vb2[u][0], vb2[u][1], vb2[u][2], vb2[u][3]), b);
+                                        swiglu_bwd8_t<ALL_GATED>(a, b, g, col, p.n_gated, da, db);
+                                        *reinterpret_cast<uint4 *>(dst) = pack8(da);
+                                        *reinterpret_cast<uint4 *>(dst + p.b_row_offset) = pack8(db);
+                                    } else {
+                                        float dx[8];
+                                        gelu_new_bwd8(a, g, dx);
+                                        *reinterpret_cast<uint4 *>(dst) = pack8(dx);
+                                    }
+                                }
+                            }
+                        }
+                    };
+                    if (EPI == EPI_DSWIGLU && ct * NC + NC > p.n_gated) bwd_store(IntC<0>{});  // tile straddles the RePaMLP mask
+                    else bwd_store(IntC<1>{});
+                } else
 #pragma unroll 4
                 for (int r = r0; r < BM; r += ROWS_PER_IT) {
                     const int prow = row_begin + r;
                     if (prow < row_end && ncols_ok > 0) {
                         const uint4 v = *reinterpret_cast<const uint4 *>(img + r * ROWB + cc * 16);
                         bf16_t *dst = p.out + (long long)prow * p.ldo + col;
-                        if (EPI == EPI_DSWIGLU || EPI == EPI_DGELU) {
-                            // v = 8 elements of dH (bf16, as the standalone path stores them); N_out % 8 == 0 here
-                            const bf16_t *abrow = p.aux + (long long)prow * p.ld_aux + col;
-                            float g[8], a[8];
-                            unpack8(v, g);
-                            unpack8(*reinterpret_cast<const uint4 *>(abrow), a);
-                            if (EPI == EPI_DSWIGLU) {
-                                float b[8], da[8], db[8];
-                                unpack8(*reinterpret_cast<const uint4 *>(abrow + p.b_row_offset), b);
-                                swiglu_bwd8(a, b, g, col, p.n_gated, da, db);
-                                *reinterpret_cast<uint4 *>(dst) = pack8(da);
-                                *reinterpret_cast<uint4 *>(dst + p.b_row_offset) = pack8(db);
-                            } else {
-                                float dx[8];
-                                gelu_new_bwd8(a, g, dx);
-                                *reinterpret_cast<uint4 *>(dst) = pack8(dx);
-                            }
-                        } else if (ncols_ok >= 8) {
+                        if (ncols_ok >= 8) {
 #if GEMM_NT_STORE
                             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
                             u32x4_t vv = {v.x, v.y, v.z, v.w};
