@@ -695,3 +695,60 @@ def test_persistent_launch_equals_one_block_per_tile(epilogue):
         else:
             want = torch.nn.functional.gelu((ab + b1[e].float()).to(torch.bfloat16).float(), approximate="tanh").to(torch.bfloat16)
         assert torch.allclose(outs[0][rows].float(), want.float(), rtol=3e-2, atol=3e-2)
+
+
+def _chunk_major_pos(offs, C):
+    """Host restatement of the chunk-major order of the pipelined expert-parallel exchange: chunk c
+    holds rows [c*k/C, (c+1)*k/C) of every expert's k kept rows, experts in order inside a chunk."""
+    E = len(offs) - 1
+    pos = [0] * offs[-1]
+    nxt = 0
+    for c in range(C):
+        for e in range(E):
+            k = offs[e + 1] - offs[e]
+            for i in range(k * c // C, k * (c + 1) // C):
+                pos[offs[e] + i] = nxt
+                nxt += 1
+    return torch.tensor(pos, dtype=torch.long)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("counts", [[5, 0, 3, 9], [1, 1, 1, 1], [0, 0, 0, 0], [700, 33, 0, 1290, 2, 64, 0, 511]])
+@pytest.mark.parametrize("C", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_ep_chunk_rows_order_is_bit_exact(counts, C, dtype):
+    """moe_ep_chunk_rows_fwd through the C ABI: send order (gathered through perm), unpack, and their round trip -- pure data
+    movement, so bit-exact; experts with no rows and experts with fewer rows than chunks included."""
+    ops = _ops()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(sum(counts) * 31 + C)
+    E, n, M = len(counts), sum(counts), 192
+    offs = [0]
+    for k in counts:
+        offs.append(offs[-1] + k)
+    S = max(n, 1)
+    x = torch.randn(S, M, generator=g).to(dtype)
+    tok = torch.randperm(S, generator=g)[:n]
+    perm = (2 * tok + torch.randint(0, 2, (n,), generator=g)).to(torch.int32)   # 2 * token + choice, as the routing kernel writes it
+    max_rows = n + 7                                                            # the buffers are sized for the worst case
+    perm_dev = torch.cat([perm, torch.full((7,), -1, dtype=torch.int32)]).to(dev)
+    offs_dev = torch.tensor(offs, dtype=torch.int32, device=dev)
+    pos = _chunk_major_pos(offs, C)
+    send = ops.ep_chunk_rows(x.to(dev), perm_dev, 1, offs_dev, C, False, max_rows)
+    torch.cuda.synchronize()
+    want = torch.empty(n, M, dtype=dtype)
+    want[pos] = x[tok]
+    assert torch.equal(send[:n].cpu(), want)
+    # no gather index: rows already compact
+    rows = torch.randn(max(max_rows, 1), M, generator=g).to(dtype)
+    send2 = ops.ep_chunk_rows(rows.to(dev), None, 0, offs_dev, C, False, max_rows)
+    want2 = torch.empty(n, M, dtype=dtype)
+    want2[pos] = rows[:n]
+    assert torch.equal(send2[:n].cpu(), want2)
+    # unpack is the inverse map, into a caller-provided buffer
+    out = torch.full((max(max_rows, 1), M), 7.0, dtype=dtype, device=dev)
+    back = ops.ep_chunk_rows(send2, None, 0, offs_dev, C, True, max_rows, out=out)
+    torch.cuda.synchronize()
+    assert back.data_ptr() == out.data_ptr()
+    assert torch.equal(back[:n].cpu(), rows[:n])
+    assert torch.all(back[n:].cpu() == 7.0)                                     # rows past the kept count are not touched
