@@ -29,6 +29,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #ifndef WG_ASYM_MF
 #define WG_ASYM_MF 4   // rows fragments of a loader wave (4 / 12 measured 2.7 % faster than 5 / 11 here: the loader chain is the critical one)
 #endif
+#ifndef WG_LPT_MAX_E
+#define WG_LPT_MAX_E 16   // local experts up to which the tile order sorts the experts by row count (O(E^2) scalar work per block)
+#endif
 #ifndef WG_PD
 #define WG_PD 2        // A fragments read ahead of the MFMAs
 #endif
@@ -118,18 +121,55 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    // inside an expert: super-rows of 4 r tiles, n tile next, r tile fastest -> the ~32 blocks an XCD runs together
-    // share 4 A panels and 8 B panels in its L2
+    // Tile order.  A block's XCD is blockIdx % 8 and the remap above hands each XCD one contiguous eighth of the order,
+    // which its 32 CUs work through on their own.  A tile's K range is its expert's row count, so with an expert-major
+    // order two XCDs got nothing but the busiest expert's tiles and two nothing but the idlest one's: under the routing
+    // skew of the bench data the launch took 1.35-1.47 x its balanced time (replayed per XCD; measured +32 %).  The order
+    // is therefore interleaved: runs of g = ceil(per_e / 8) tiles of each expert in turn, so that every XCD's eighth
+    // holds an equal share of every expert, and inside a round of E runs the experts come longest K range first (what a
+    // greedy list schedule wants).  Inside an expert the order is unchanged: super-rows of 4 r tiles, n tile next, r
+    // tile fastest -> the blocks an XCD runs together still share A and B panels in its L2.
     const int per_e = p.r_tiles * p.n_tiles;
-    const int expert = swz / per_e;
-    const int rem = swz - expert * per_e;
+    const int E = p.n_experts;
+    const int g = (per_e + 7) >> 3;
+    const int nb = (per_e + g - 1) / g;
+    const int full = (nb - 1) * E * g;
+    int q, rem;  // q: position of the expert inside its round, rem: tile index inside the expert
+    if (swz < full) {
+        const int b = swz / (E * g), w = swz - b * (E * g);
+        q = w / g;
+        rem = b * g + (w - q * g);
+    } else {
+        const int last = per_e - (nb - 1) * g, w = swz - full;
+        q = w / last;
+        rem = (nb - 1) * g + (w - q * last);
+    }
+    if (q >= E) return;  // never (grid = E * per_e); keeps the loops below in bounds
+    int expert = q;
+    if (E <= WG_LPT_MAX_E) {
+        // expert with rank q when sorted by rows, descending (ties: lower index first); all scalar work
+        const int per = p.G / E;
+        int mine = -1;
+        for (int e = 0; e < E && mine < 0; ++e) {
+            int rows_e = 0;
+            for (int src = 0; src < per; ++src) rows_e += p.group_offsets[src * E + e + 1] - p.group_offsets[src * E + e];
+            int rank = 0;
+            for (int f = 0; f < E; ++f) {
+                int rows_f = 0;
+                for (int src = 0; src < per; ++src) rows_f += p.group_offsets[src * E + f + 1] - p.group_offsets[src * E + f];
+                rank += (rows_f > rows_e || (rows_f == rows_e && f < e)) ? 1 : 0;
+            }
+            if (rank == q) mine = e;
+        }
+        expert = mine;
+    }
     const int per_sr = 4 * p.n_tiles;
     const int sr = rem / per_sr;
     const int rem2 = rem - sr * per_sr;
     const int rows_in = min(4, p.r_tiles - sr * 4);
     const int nt = rem2 / rows_in;
     const int rt = sr * 4 + (rem2 - nt * rows_in);
-    if (expert >= p.n_experts) return;
+    if (expert < 0 || expert >= p.n_experts) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;

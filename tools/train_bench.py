@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--kind", default="stablelm")
+    ap.add_argument("--skew", type=int, default=0, help="1: bench.py's input (image rows share a direction: experts get 30/31/19/20 % of the rows)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(1234)
@@ -32,7 +33,12 @@ def main():
     moe.deepspeed_moe.gate.wg.weight.data = (torch.randn(4, M, device=dev) * 0.02)
     moe.train()
     S = a.batch * a.tokens
-    x = torch.randn(a.batch, a.tokens, M, device=dev).to(torch.bfloat16)
+    x = torch.randn(a.batch, a.tokens, M, device=dev)
+    if a.skew:
+        g = torch.Generator().manual_seed(7)
+        u = torch.randn(M, generator=g)
+        x[:, :(a.tokens * 576) // 704] += 0.5 * (u * (M ** 0.5) / u.norm()).to(dev)
+    x = x.to(torch.bfloat16)
     R = torch.randn(a.batch, a.tokens, M, device=dev).to(torch.bfloat16)
 
     def step():
@@ -59,7 +65,8 @@ def main():
     flops_f = 2 * S * 6 * M * I if a.kind == "stablelm" else 2 * S * 4 * M * I
     print(json.dumps({"S": S, "kind": a.kind, "fwd_ms": round(f, 3), "bwd_ms": round(b, 3),
                       "fwd_tflops": round(flops_f / f / 1e9, 1), "bwd_tflops": round(2 * flops_f / b / 1e9, 1),
-                      "train_tokens_per_s": round(S / (f + b) * 1e3)}))
+                      "train_tokens_per_s": round(S / (f + b) * 1e3),
+                      "exp_counts": moe.deepspeed_moe.exp_counts.tolist()}))
 
 
 if __name__ == "__main__":
