@@ -298,7 +298,8 @@ int moe_gate_bwd(const void *x_bf16, const float *logits, const int32_t *expert_
                  float *dlogits, float *dwg, void *workspace, size_t ws_bytes, void *stream);
 
 /* moe_dispatch_bwd: dx[s] = bf16( sum_j da_rows[pos(s,j)] + sum_e dlogits[s,e] * wg[e] ), the backward of the dispatch
- * einsum plus the gate's F.linear w.r.t. its input.  dlogits / wg may both be NULL (no gate term).  dx [S,M] bf16. */
+ * einsum plus the gate's F.linear w.r.t. its input.  dlogits / wg may both be NULL (no gate term).  dx [S,M] bf16.
+ * da_rows must hold at least one row: row 0 is read (and masked out) in place of a dropped choice. */
 int moe_dispatch_bwd(const void *da_rows, const int32_t *expert_idx, const int32_t *slot, const int32_t *expert_offsets,
                      const float *dlogits, const void *wg, int wg_is_bf16, int S, int M, int E, int top_k, void *dx,
                      void *stream);
