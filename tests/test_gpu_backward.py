@@ -58,6 +58,8 @@ def _run_both(kind, M, I, E, shape, cf, noisy, seed=11, aux_coef=0.3):
     # several 256-wide tiles in every GEMM of the step (weight gradients: 2 x 3 and 6 x 2 tiles per expert)
     ("stablelm", 512, 768, 4, (2, 333), 1.5),
     ("phi", 320, 1024, 2, (1, 700), 1.0),
+    # more than 16 local experts: the weight-gradient tile order keeps the experts in index order (no ranking by rows)
+    ("stablelm", 64, 128, 24, (2, 190), 2.0),
 ])
 @pytest.mark.parametrize("noisy", [False, True])
 def test_block_gradients_vs_oracle_autograd(kind, M, I, E, shape, cf, noisy):
