@@ -140,3 +140,43 @@ def test_cfg1_shape_backward_finite_and_linear():
         assert float(a.abs().max()) > 0
         # power-of-two scaling of the upstream gradient is exact in bf16/fp32
         assert torch.equal(2.0 * a, b)
+
+
+@pytest.mark.parametrize("reentrant", [True, False])
+def test_activation_checkpointing_recompute_matches(reentrant):
+    """The reference fine-tunes with --gradient_checkpointing True (scripts/v1/stablelm/finetune_moe.sh:44): every decoder
+    layer runs under torch.utils.checkpoint, so the block's forward is re-run inside backward.  The recomputation must take
+    the same routing decisions (the 2nd-expert Gumbel seed comes from torch's CPU generator, whose state checkpoint restores)
+    and give the gradients of the plain run, bit for bit."""
+    from torch.utils.checkpoint import checkpoint
+    import moe_llava_amd
+    from moe_llava_amd.expert_mlps import StableLMMLP
+    M, I, E = 128, 256, 4
+    torch.manual_seed(3)
+    moe = moe_llava_amd.MoE(M, StableLMMLP(M, I), num_experts=E, k=2, capacity_factor=1.0, min_capacity=0)
+    moe = moe.to(torch.bfloat16).to(DEV).train()           # top2_2nd_expert_sampling stays on (upstream default): noisy routing
+    for p in moe.deepspeed_moe.experts.parameters():
+        p.data.normal_(0, 0.05)
+    x = torch.randn(2, 150, M, device=DEV).to(torch.bfloat16)
+    R = torch.randn(2, 150, M, device=DEV).to(torch.bfloat16)
+
+    def layer(h):                                          # the decoder glue of llava_stablelm_moe.py:163-170, reduced
+        out, l_aux, _ = moe(h)
+        return h + out, l_aux
+
+    def run(ckpt):
+        moe.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        torch.manual_seed(77)                              # same generator state in front of both runs
+        if ckpt:
+            y, l_aux = checkpoint(layer, xg, use_reentrant=reentrant)
+        else:
+            y, l_aux = layer(xg)
+        ((y.float() * R.float()).sum() + 0.01 * l_aux).backward()
+        torch.cuda.synchronize()
+        return [y.detach().clone(), xg.grad.clone()] + [p.grad.clone() for p in moe.parameters()]
+
+    plain, ck = run(False), run(True)
+    assert len(plain) == len(ck)
+    for a, b in zip(plain, ck):
+        assert torch.equal(a, b)
