@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 6
+#define MOE_ABI_VERSION 7
 
 /* Element type of the 16-bit activations, expert weights and biases of a forward call (`dtype` arguments below).
  * bf16 is what the reference trains and serves with (--bf16); fp16 is what its inference loader builds the model in
@@ -68,9 +68,17 @@ const char *moe_last_error(void);
  * moe_gate_logits_fwd: logits[s,e] = sum_m float(x[s,m]) * float(wg[e,m])  (fp32 accumulate).
  *   x  [S,M] bf16 or fp16 (dtype = MOE_DTYPE_*), row-major (row stride M), M % 8 == 0, E <= 64.
  *   wg [E,M] of type wg_dtype = MOE_WG_F32, or MOE_WG_BF16 / MOE_WG_F16 matching dtype.
+ *   jitter_seed (ABI v7): 0 = none.  Non-zero = noisy_gate_policy 'Jitter' while training (upstream
+ *       multiplicative_jitter in TopKGate.forward): float(x[s,m]) is multiplied by a sample of U(1 - 1e-2, 1 + 1e-2)
+ *       that is a function of (jitter_seed, s, m) only; moe_gate_bwd / moe_dispatch_bwd take the same seed and
+ *       regenerate the same factors, moe_gate_jitter_fill writes them out.  No [S,M] noise tensor exists.
  */
 int moe_gate_logits_fwd(const void *x, const void *wg, int wg_dtype, float *logits,
-                        int S, int M, int E, int dtype, void *stream);
+                        int S, int M, int E, int dtype, uint64_t jitter_seed, void *stream);
+
+/* moe_gate_jitter_fill: out[s,m] (fp32, [S,M]) = the factor the kernels use for (jitter_seed, s, m); for tests and
+ * inspection (upstream: the `uniform(x.shape)` sample inside multiplicative_jitter).  jitter_seed != 0, M % 8 == 0. */
+int moe_gate_jitter_fill(uint64_t jitter_seed, int S, int M, float *out, void *stream);
 
 /* bytes of workspace moe_routing_top2_fwd needs for S tokens and E experts */
 size_t moe_routing_workspace_bytes(int S, int E);
@@ -291,18 +299,20 @@ size_t moe_gate_bwd_workspace_bytes(int S, int M, int E);
  *   dweight [S,top_k] fp32 (from moe_combine_bwd), dl_aux device pointer to the gradient of l_aux (or NULL = 0)
  *   dlogits [S,E] fp32 out: through the renormalisation g_j / clamp(g_1+g_2, eps), the post-drop masks, the
  *           l_aux term E * ce[e] / S and the softmax (the argmax / capacity decisions carry no gradient)
- *   dwg     [E,M] fp32 out = dlogits^T @ float(x)   (deterministic two-stage reduction)
+ *   dwg     [E,M] fp32 out = dlogits^T @ (float(x) * jitter)   (deterministic two-stage reduction)
+ *   jitter_seed: the seed given to moe_gate_logits_fwd (0 = the gate input was not jittered)
  * The gradient w.r.t. x through the gate is added by moe_dispatch_bwd. */
 int moe_gate_bwd(const void *x_bf16, const float *logits, const int32_t *expert_idx, const int32_t *slot,
                  const float *dweight, const float *dl_aux, const int32_t *used_token, int S, int M, int E, int top_k,
-                 float *dlogits, float *dwg, void *workspace, size_t ws_bytes, void *stream);
+                 float *dlogits, float *dwg, void *workspace, size_t ws_bytes, uint64_t jitter_seed, void *stream);
 
-/* moe_dispatch_bwd: dx[s] = bf16( sum_j da_rows[pos(s,j)] + sum_e dlogits[s,e] * wg[e] ), the backward of the dispatch
- * einsum plus the gate's F.linear w.r.t. its input.  dlogits / wg may both be NULL (no gate term).  dx [S,M] bf16.
+/* moe_dispatch_bwd: dx[s] = bf16( sum_j da_rows[pos(s,j)] + jitter[s] * sum_e dlogits[s,e] * wg[e] ), the backward of
+ * the dispatch einsum plus the gate's F.linear w.r.t. its input (jitter = 1 when jitter_seed == 0, else the factors of
+ * moe_gate_logits_fwd's seed).  dlogits / wg may both be NULL (no gate term; jitter_seed must be 0).  dx [S,M] bf16.
  * da_rows must hold at least one row: row 0 is read (and masked out) in place of a dropped choice. */
 int moe_dispatch_bwd(const void *da_rows, const int32_t *expert_idx, const int32_t *slot, const int32_t *expert_offsets,
                      const float *dlogits, const void *wg, int wg_is_bf16, int S, int M, int E, int top_k, void *dx,
-                     void *stream);
+                     uint64_t jitter_seed, void *stream);
 
 #ifdef __cplusplus
 }

@@ -14,13 +14,14 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # MOE_GFX950_LIB points the loader at another build of the same ABI (kernel A/B experiments, tools/variants)
 LIB_PATH = os.environ.get("MOE_GFX950_LIB") or os.path.join(_PKG, "libmoe_gfx950.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # (name, restype, argtypes) -- must mirror include/moe_gfx950.h exactly
 _SIGNATURES = [
     ("moe_abi_version", c_int, []),
     ("moe_last_error", c_char_p, []),
-    ("moe_gate_logits_fwd", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    ("moe_gate_logits_fwd", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_uint64, c_void_p]),
+    ("moe_gate_jitter_fill", c_int, [c_uint64, c_int, c_int, c_void_p, c_void_p]),
     ("moe_routing_workspace_bytes", c_size_t, [c_int, c_int]),
     ("moe_routing_top2_fwd", c_int,
      [c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -68,10 +69,10 @@ _SIGNATURES = [
     ("moe_gate_bwd_workspace_bytes", c_size_t, [c_int, c_int, c_int]),
     ("moe_gate_bwd", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-      c_void_p, c_void_p, c_size_t, c_void_p]),
+      c_void_p, c_void_p, c_size_t, c_uint64, c_void_p]),
     ("moe_dispatch_bwd", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
-      c_void_p]),
+      c_uint64, c_void_p]),
 ]
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]

@@ -194,10 +194,11 @@ __global__ __launch_bounds__(256) void routing_top2_bwd_kernel(const float *__re
 // ------------------------------------------------------------------------------------------------
 // gate weight gradient: dwg[e,m] = sum_s dlogits[s,e] * float(x[s,m]); two deterministic stages
 // ------------------------------------------------------------------------------------------------
-template <int EC>
+// JIT: the gate saw float(x) * jitter(jitter_seed, row, column) (noisy_gate_policy = 'Jitter'), so that product is the operand
+template <int EC, bool JIT>
 __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const bf16_t *__restrict__ x, const float *__restrict__ dlogits,
                                                                  int S, int M, int E, int rows_per_chunk,
-                                                                 float *__restrict__ partial) {
+                                                                 float *__restrict__ partial, unsigned long long jitter_seed) {
     const int col0 = blockIdx.y * 2048 + threadIdx.x * 8;
     if (col0 >= M) return;
     const int e0 = blockIdx.z * EC;
@@ -220,6 +221,13 @@ __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const bf16_t *_
         for (int u = 0; u < RU; ++u) {
             float xv[8];
             unpack8(raw[u], xv);
+            if (JIT) {
+                float jf[8];
+                jitter4(jitter_seed, r + u, col0, jf);
+                jitter4(jitter_seed, r + u, col0 + 4, jf + 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xv[i] *= jf[i];
+            }
 #pragma unroll
             for (int e = 0; e < EC; ++e) {
                 const float d = (e0 + e < E) ? dlogits[(long long)(r + u) * E + e0 + e] : 0.f;
@@ -231,6 +239,13 @@ __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const bf16_t *_
     for (; r < r1; ++r) {
         float xv[8];
         unpack8(*reinterpret_cast<const uint4 *>(x + (long long)r * M + col0), xv);
+        if (JIT) {
+            float jf[8];
+            jitter4(jitter_seed, r, col0, jf);
+            jitter4(jitter_seed, r, col0 + 4, jf + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xv[i] *= jf[i];
+        }
 #pragma unroll
         for (int e = 0; e < EC; ++e) {
             const float d = (e0 + e < E) ? dlogits[(long long)r * E + e0 + e] : 0.f;
@@ -282,11 +297,14 @@ constexpr int DB_TOK = 4;  // tokens per wave pass of dispatch_bwd_kernel
 // per wave re-read the 32 KiB of wg from L2 per 12 KiB of row data), and the 2 * DB_TOK row loads of a chunk are
 // issued together from always-valid addresses (a dropped slot reads row 0 and is masked by a select, never by a
 // branch around the load).  Per output element the terms are added in the old order: same bits.
-template <int TOPK, bool WG_BF16>
+// JIT (noisy_gate_policy = 'Jitter'): the gate term is the gradient w.r.t. float(x) * jitter, so it is multiplied by the
+// same factors before it joins the row sums.
+template <int TOPK, bool WG_BF16, bool JIT>
 __global__ __launch_bounds__(256) void dispatch_bwd_kernel(const bf16_t *__restrict__ da_rows, const int *__restrict__ expert_idx,
                                                            const int *__restrict__ slot, const int *__restrict__ expert_offsets,
                                                            const float *__restrict__ dlogits, const void *__restrict__ wg,
-                                                           int S, int M, int E, bf16_t *__restrict__ dx) {
+                                                           int S, int M, int E, bf16_t *__restrict__ dx,
+                                                           unsigned long long jitter_seed) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunks = M >> 3;
     for (int s0 = (blockIdx.x * 4 + wave) * DB_TOK; s0 < S; s0 += gridDim.x * 4 * DB_TOK) {
@@ -324,6 +342,13 @@ __global__ __launch_bounds__(256) void dispatch_bwd_kernel(const bf16_t *__restr
                 }
             }
             if (dlogits) {
+                float gacc[JIT ? DB_TOK : 1][8];  // JIT: the gate term apart, scaled by the jitter factors at the end
+                if (JIT) {
+#pragma unroll
+                    for (int t = 0; t < DB_TOK; ++t)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) gacc[JIT ? t : 0][i] = 0.f;
+                }
                 for (int e = 0; e < E; ++e) {
                     float wv[8];
                     if (WG_BF16) {
@@ -338,7 +363,20 @@ __global__ __launch_bounds__(256) void dispatch_bwd_kernel(const bf16_t *__restr
                     for (int t = 0; t < DB_TOK; ++t) {
                         const float d = dlogits[(long long)tok[t] * E + e];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[t][i] += d * wv[i];
+                        for (int i = 0; i < 8; ++i) {
+                            if (JIT) gacc[JIT ? t : 0][i] += d * wv[i];
+                            else acc[t][i] += d * wv[i];
+                        }
+                    }
+                }
+                if (JIT) {
+#pragma unroll
+                    for (int t = 0; t < DB_TOK; ++t) {
+                        float jf[8];
+                        jitter4(jitter_seed, tok[t], c * 8, jf);
+                        jitter4(jitter_seed, tok[t], c * 8 + 4, jf + 4);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[t][i] += gacc[JIT ? t : 0][i] * jf[i];
                     }
                 }
             }
@@ -511,7 +549,8 @@ extern "C" size_t moe_gate_bwd_workspace_bytes(int S, int M, int E) {
 
 extern "C" int moe_gate_bwd(const void *x, const float *logits, const int32_t *expert_idx, const int32_t *slot,
                             const float *dweight, const float *dl_aux, const int32_t *used_token, int S, int M, int E,
-                            int top_k, float *dlogits, float *dwg, void *workspace, size_t ws_bytes, void *stream) {
+                            int top_k, float *dlogits, float *dwg, void *workspace, size_t ws_bytes, uint64_t jitter_seed,
+                            void *stream) {
     if (!x || !logits || !expert_idx || !slot || !dweight || !dlogits || !dwg || !workspace)
         return fail(MOE_ERR_ARG, "moe_gate_bwd: null pointer");
     if (S < 1 || M <= 0 || (M & 7) || E < 1 || E > 64 || (top_k != 1 && top_k != 2) || (top_k == 2 && E < 2))
@@ -548,13 +587,18 @@ extern "C" int moe_gate_bwd(const void *x, const float *logits, const int32_t *e
     if (rc) return rc;
     const int rpc = gate_rows_per_chunk(S);
     const int nchunks = (S + rpc - 1) / rpc;
+    const unsigned long long jseed = (unsigned long long)jitter_seed;
+#define LAUNCH_GW(EC, JIT, GZ)                                                                                          \
+    hipLaunchKernelGGL((gate_wgrad_partial_kernel<EC, JIT>), dim3(nchunks, (M + 2047) / 2048, GZ), dim3(256), 0, st,    \
+                       (const bf16_t *)x, dlogits, S, M, E, rpc, partial, jseed)
     if (E <= 4) {
-        hipLaunchKernelGGL((gate_wgrad_partial_kernel<4>), dim3(nchunks, (M + 2047) / 2048, 1), dim3(256), 0, st,
-                           (const bf16_t *)x, dlogits, S, M, E, rpc, partial);
+        if (jseed) LAUNCH_GW(4, true, 1);
+        else LAUNCH_GW(4, false, 1);
     } else {
-        hipLaunchKernelGGL((gate_wgrad_partial_kernel<8>), dim3(nchunks, (M + 2047) / 2048, (E + 7) / 8), dim3(256), 0, st,
-                           (const bf16_t *)x, dlogits, S, M, E, rpc, partial);
+        if (jseed) LAUNCH_GW(8, true, (E + 7) / 8);
+        else LAUNCH_GW(8, false, (E + 7) / 8);
     }
+#undef LAUNCH_GW
     rc = check_launch("gate_wgrad_partial_kernel");
     if (rc) return rc;
     const long long EM = (long long)E * M;
@@ -565,7 +609,7 @@ extern "C" int moe_gate_bwd(const void *x, const float *logits, const int32_t *e
 
 extern "C" int moe_dispatch_bwd(const void *da_rows, const int32_t *expert_idx, const int32_t *slot,
                                 const int32_t *expert_offsets, const float *dlogits, const void *wg, int wg_is_bf16, int S,
-                                int M, int E, int top_k, void *dx, void *stream) {
+                                int M, int E, int top_k, void *dx, uint64_t jitter_seed, void *stream) {
     if (!da_rows || !expert_idx || !slot || !expert_offsets || !dx) return fail(MOE_ERR_ARG, "moe_dispatch_bwd: null pointer");
     if ((dlogits != nullptr) != (wg != nullptr))
         return fail(MOE_ERR_ARG, "moe_dispatch_bwd: dlogits and wg must be given together");
@@ -577,9 +621,17 @@ extern "C" int moe_dispatch_bwd(const void *da_rows, const int32_t *expert_idx, 
     const int per_block = 4 * DB_TOK;  // tokens per block pass
     const int grid = (S + per_block - 1) / per_block < 16384 ? (S + per_block - 1) / per_block : 16384;
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_DB(TK, BF)                                                                                             \
-    hipLaunchKernelGGL((dispatch_bwd_kernel<TK, BF>), dim3(grid), dim3(256), 0, st, (const bf16_t *)da_rows, expert_idx, \
-                       slot, expert_offsets, dlogits, wg, S, M, E, (bf16_t *)dx)
+    const unsigned long long jseed = (unsigned long long)jitter_seed;
+    if (jseed && !dlogits) return fail(MOE_ERR_ARG, "moe_dispatch_bwd: a jitter seed needs the gate term (dlogits, wg)");
+#define LAUNCH_DB(TK, BF)                                                                                              \
+    do {                                                                                                               \
+        if (jseed) hipLaunchKernelGGL((dispatch_bwd_kernel<TK, BF, true>), dim3(grid), dim3(256), 0, st,               \
+                                      (const bf16_t *)da_rows, expert_idx, slot, expert_offsets, dlogits, wg, S, M, E, \
+                                      (bf16_t *)dx, jseed);                                                            \
+        else hipLaunchKernelGGL((dispatch_bwd_kernel<TK, BF, false>), dim3(grid), dim3(256), 0, st,                    \
+                                (const bf16_t *)da_rows, expert_idx, slot, expert_offsets, dlogits, wg, S, M, E,       \
+                                (bf16_t *)dx, 0ull);                                                                   \
+    } while (0)
     if (top_k == 2) {
         if (wg_is_bf16) LAUNCH_DB(2, true);
         else LAUNCH_DB(2, false);

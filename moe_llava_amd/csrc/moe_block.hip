@@ -23,7 +23,7 @@ static int block_top2(const void *x, int dtype, const void *wg, int wg_dtype, fl
                                      drop_tokens, expert_idx, slot, weight, exp_counts, kept_counts, expert_offsets, perm,
                                      l_aux, stream);
     } else {
-        rc = moe_gate_logits_fwd(x, wg, wg_dtype, logits, S, M, E, dtype, stream);
+        rc = moe_gate_logits_fwd(x, wg, wg_dtype, logits, S, M, E, dtype, 0, stream);
         if (rc) return rc;
         rc = noise_seed_dev
                  ? moe_routing_top2_fwd_dseed(logits, noise_seed_dev, S, E, capacity, drop_tokens, expert_idx, slot, weight,

@@ -67,6 +67,34 @@ __device__ __forceinline__ uint4 pack8(const float *f) {
     return o;
 }
 
+// Counter-based Philox4x32-10 (Salmon et al.): the per-(token, expert) Gumbel noise of the routing kernels and the gate
+// jitter below are functions of (seed, counter) only, independent of the launch geometry.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// noisy_gate_policy = 'Jitter' (training only): upstream multiplies the fp32 gate input elementwise by a sample of
+// U(1 - eps, 1 + eps), eps = 1e-2 (deepspeed multiplicative_jitter).  The factors are never materialised: the gate GEMV
+// and the two backward kernels that need them regenerate them from (seed, token, column / 4).  f[0..3] = factors of
+// columns m0 .. m0 + 3 (m0 a multiple of 4) of one token.
+constexpr float JITTER_EPS = 1e-2f;
+__device__ __forceinline__ void jitter4(unsigned long long seed, int token, int m0, float *f) {
+    const uint4 r = philox4x32_10(make_uint4((unsigned)token, (unsigned)(m0 >> 2), 0x4a495454u, 0u),
+                                  make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+    const unsigned u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        f[i] = (1.0f - JITTER_EPS) + (2.0f * JITTER_EPS) * ((float)(u[i] >> 8) * 5.9604644775390625e-08f);  // [1 - eps, 1 + eps)
+}
+
 // ---- element type of the activations / expert weights: bf16 (training, --bf16 serving) or fp16 (the reference's
 //      inference loader, moellava/model/builder.py:70,475).  Elt<DT> holds every conversion and rounding point, so a
 //      kernel templated on DT rounds to the tensor dtype exactly where torch's 16-bit modules do. ----

@@ -43,9 +43,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // rows row0 .. row0 + R - 1 (clamped to S - 1, stored only when < S) x E experts by ONE wave.  The result of a row
 // does not depend on R or on which wave computes it: a fixed per-lane fmaf chain over M, then the wave butterfly.
 // DT = element type of x; WG16: wg has that same 16-bit type (otherwise fp32).
-template <int EMAX, int R, bool WG16, int DT>
+// JIT: the fp32 gate input is multiplied by the jitter factors of (jitter_seed, row, column) first (training with
+// noisy_gate_policy = 'Jitter'; moe_common.h).
+template <int EMAX, int R, bool WG16, int DT, bool JIT = false>
 __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const void *__restrict__ wg,
-                                          float *__restrict__ logits, int S, int M, int E, int row0, int lane) {
+                                          float *__restrict__ logits, int S, int M, int E, int row0, int lane,
+                                          unsigned long long jitter_seed = 0ull) {
     float acc[R][EMAX];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -59,6 +62,13 @@ __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const vo
             int row = row0 + r;
             if (row > S - 1) row = S - 1;
             unpack8_t<DT>(*reinterpret_cast<const uint4 *>(x + (size_t)row * M + m0), xf[r]);
+            if (JIT) {
+                float jf[8];
+                jitter4(jitter_seed, row, m0, jf);
+                jitter4(jitter_seed, row, m0 + 4, jf + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[r][j] *= jf[j];
+            }
         }
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) {
@@ -90,13 +100,25 @@ __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const vo
         }
 }
 
-template <int EMAX, int R, bool WG16, int DT>
+template <int EMAX, int R, bool WG16, int DT, bool JIT>
 __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16_t *__restrict__ x, const void *__restrict__ wg,
-                                                          float *__restrict__ logits, int S, int M, int E) {
+                                                          float *__restrict__ logits, int S, int M, int E,
+                                                          unsigned long long jitter_seed) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + wave) * R;
     if (row0 >= S) return;
-    gate_rows<EMAX, R, WG16, DT>(x, wg, logits, S, M, E, row0, lane);
+    gate_rows<EMAX, R, WG16, DT, JIT>(x, wg, logits, S, M, E, row0, lane, jitter_seed);
+}
+
+// the jitter factors themselves, [S, M] fp32 (tests and inspection; the kernels never read such a tensor)
+__global__ __launch_bounds__(256) void jitter_fill_kernel(unsigned long long seed, int S, int M, float *__restrict__ out) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread = 4 columns of one token
+    const int per_row = M >> 2;
+    if (q >= (long long)S * per_row) return;
+    const int s = (int)(q / per_row), m0 = (int)(q - (long long)s * per_row) * 4;
+    float f[4];
+    jitter4(seed, s, m0, f);
+    *reinterpret_cast<float4 *>(out + (long long)s * M + m0) = make_float4(f[0], f[1], f[2], f[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -104,17 +126,6 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16_t *__restri
 // the caller's seed, counter = (token, expert / 4), so the sample of (token, expert) does not depend on the
 // launch geometry.  Upstream draws Gumbel(0,1).rsample() per (token, expert); only the distribution matters.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
-    return c;
-}
 __device__ __forceinline__ float gumbel_from_bits(unsigned x) {
     const float u = ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f;  // (0,1), 23 random bits, never 0 or 1
     return -logf(-logf(u));
@@ -616,7 +627,7 @@ static int gate_types_ok(const char *fn, int wg_dtype, int dtype, bool *wg16) {
 }
 
 extern "C" int moe_gate_logits_fwd(const void *x, const void *wg, int wg_dtype, float *logits, int S, int M, int E,
-                                   int dtype, void *stream) {
+                                   int dtype, uint64_t jitter_seed, void *stream) {
     if (!x || !wg || !logits) return fail(MOE_ERR_ARG, "moe_gate_logits_fwd: null pointer");
     bool wg16 = false;
     if (int rc = gate_types_ok("moe_gate_logits_fwd", wg_dtype, dtype, &wg16)) return rc;
@@ -626,8 +637,14 @@ extern "C" int moe_gate_logits_fwd(const void *x, const void *wg, int wg_dtype, 
     if (S == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const bf16_t *xp = (const bf16_t *)x;
-#define LAUNCH_GATE_T(EM, RR, W16, DT_)                                                                          \
-    hipLaunchKernelGGL((gate_logits_kernel<EM, RR, W16, DT_>), grid, dim3(256), 0, st, xp, wg, logits, S, M, E)
+    const unsigned long long jseed = (unsigned long long)jitter_seed;
+#define LAUNCH_GATE_T(EM, RR, W16, DT_)                                                                                 \
+    do {                                                                                                                \
+        if (jseed) hipLaunchKernelGGL((gate_logits_kernel<EM, RR, W16, DT_, true>), grid, dim3(256), 0, st, xp, wg,     \
+                                      logits, S, M, E, jseed);                                                          \
+        else hipLaunchKernelGGL((gate_logits_kernel<EM, RR, W16, DT_, false>), grid, dim3(256), 0, st, xp, wg, logits,  \
+                                S, M, E, 0ull);                                                                         \
+    } while (0)
 #define LAUNCH_GATE(EM, RR)                                                                                      \
     do {                                                                                                         \
         const int rows_per_block = 4 * RR;                                                                       \
@@ -648,6 +665,18 @@ extern "C" int moe_gate_logits_fwd(const void *x, const void *wg, int wg_dtype, 
 #undef LAUNCH_GATE
 #undef LAUNCH_GATE_T
     return check_launch("gate_logits_kernel");
+}
+
+extern "C" int moe_gate_jitter_fill(uint64_t jitter_seed, int S, int M, float *out, void *stream) {
+    if (!out) return fail(MOE_ERR_ARG, "moe_gate_jitter_fill: null pointer");
+    if (S < 0 || M <= 0 || (M & 7) || !jitter_seed)
+        return fail(MOE_ERR_SHAPE, "moe_gate_jitter_fill: need S>=0, M%%8==0 and a non-zero seed (S=%d M=%d)", S, M);
+    if (!aligned16(out)) return fail(MOE_ERR_ALIGN, "moe_gate_jitter_fill: out not 16-byte aligned");
+    if (S == 0) return 0;
+    const long long n = (long long)S * (M >> 2);
+    hipLaunchKernelGGL(jitter_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long)jitter_seed, S, M, out);
+    return check_launch("jitter_fill_kernel");
 }
 
 extern "C" size_t moe_routing_workspace_bytes(int S, int E) {

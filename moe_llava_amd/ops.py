@@ -210,8 +210,10 @@ class Routing:
     l_aux = property(lambda self: self._view("l_aux"))
 
 
-def gate_logits(x: Tensor, wg_weight: Tensor) -> Tensor:
-    """logits = x.float() @ wg.float().T  ([S,E] fp32) -- TopKGate.forward's F.linear."""
+def gate_logits(x: Tensor, wg_weight: Tensor, jitter_seed: int = 0) -> Tensor:
+    """logits = x.float() @ wg.float().T  ([S,E] fp32) -- TopKGate.forward's F.linear.
+    ``jitter_seed`` != 0: x.float() is first multiplied by the U(1 - 1e-2, 1 + 1e-2) factors of that seed
+    (noisy_gate_policy='Jitter' while training; ``gate_jitter`` returns the factors)."""
     _need(x, "x", HALF_DTYPES, 2)
     wgd = _wg_dt(wg_weight, x)
     _need(wg_weight, "wg.weight", wg_weight.dtype, 2)
@@ -223,9 +225,19 @@ def gate_logits(x: Tensor, wg_weight: Tensor) -> Tensor:
     lib = _lib.load()
     with _on(x.device):
         rc = lib.moe_gate_logits_fwd(x.data_ptr(), wg_weight.data_ptr(), wgd, logits.data_ptr(), S, M, E, _dt(x),
-                                     _stream_ptr(x))
+                                     int(jitter_seed), _stream_ptr(x))
     _lib.check(rc, "moe_gate_logits_fwd")
     return logits
+
+
+def gate_jitter(jitter_seed: int, S: int, M: int, device) -> Tensor:
+    """[S,M] fp32: the multiplicative jitter factors the gate kernels derive from ``jitter_seed`` (tests, inspection)."""
+    out = torch.empty((S, M), dtype=torch.float32, device=device)
+    lib = _lib.load()
+    with _on(out.device):
+        rc = lib.moe_gate_jitter_fill(int(jitter_seed), S, M, out.data_ptr(), _stream_ptr(out))
+    _lib.check(rc, "moe_gate_jitter_fill")
+    return out
 
 
 def routing_top2(logits: Tensor, capacity: int, noise: Optional[Tensor] = None,
@@ -616,8 +628,9 @@ def combine_bwd(dout: Tensor, y: Tensor, r: Routing, S: int, M: int):
     return dy, dweight
 
 
-def gate_bwd(x: Tensor, logits: Tensor, r: Routing, dweight: Tensor, dl_aux: Optional[Tensor]):
-    """(dlogits [S,E] fp32, dwg [E,M] fp32) -- backward of top2gating and of the gate's F.linear w.r.t. wg."""
+def gate_bwd(x: Tensor, logits: Tensor, r: Routing, dweight: Tensor, dl_aux: Optional[Tensor], jitter_seed: int = 0):
+    """(dlogits [S,E] fp32, dwg [E,M] fp32) -- backward of top2gating and of the gate's F.linear w.r.t. wg
+    (``jitter_seed``: the seed the forward gate call was given)."""
     _need(x, "x", torch.bfloat16, 2)
     _need(logits, "logits", torch.float32, 2)
     _need(dweight, "dweight", torch.float32, 2)
@@ -634,14 +647,15 @@ def gate_bwd(x: Tensor, logits: Tensor, r: Routing, dweight: Tensor, dl_aux: Opt
         rc = lib.moe_gate_bwd(x.data_ptr(), logits.data_ptr(), r.ptr("expert_idx"), r.ptr("slot"),
                               dweight.data_ptr(), dl_aux.data_ptr() if dl_aux is not None else None,
                               r.used_token.data_ptr() if r.used_token is not None else None, S, M, E, r.top_k,
-                              dlogits.data_ptr(), dwg.data_ptr(), ws.data_ptr(), nws, _stream_ptr(x))
+                              dlogits.data_ptr(), dwg.data_ptr(), ws.data_ptr(), nws, int(jitter_seed), _stream_ptr(x))
     _lib.check(rc, "moe_gate_bwd")
     return dlogits, dwg
 
 
 def dispatch_bwd(da_rows: Tensor, r: Routing, dlogits: Optional[Tensor], wg_weight: Optional[Tensor],
-                 S: int, M: int) -> Tensor:
-    """dx [S,M] bf16: sum of the token's compact-row gradients + the gate term dlogits @ wg."""
+                 S: int, M: int, jitter_seed: int = 0) -> Tensor:
+    """dx [S,M] bf16: sum of the token's compact-row gradients + the gate term dlogits @ wg (times the jitter factors of
+    ``jitter_seed`` when the forward gate call had one)."""
     _need(da_rows, "da_rows", torch.bfloat16, 2)
     E = r.E
     dx = torch.empty((S, M), dtype=torch.bfloat16, device=da_rows.device)
@@ -652,6 +666,6 @@ def dispatch_bwd(da_rows: Tensor, r: Routing, dlogits: Optional[Tensor], wg_weig
                                   dlogits.data_ptr() if dlogits is not None else None,
                                   wg_weight.data_ptr() if wg_weight is not None else None,
                                   int(wg_weight is not None and wg_weight.dtype == torch.bfloat16), S, M, E,
-                                  r.top_k, dx.data_ptr(), _stream_ptr(da_rows))
+                                  r.top_k, dx.data_ptr(), int(jitter_seed), _stream_ptr(da_rows))
     _lib.check(rc, "moe_dispatch_bwd")
     return dx

@@ -60,12 +60,15 @@ class TopKGate(nn.Module):
         #: optional [S,E] fp32 uniforms for top-1 random token selection (parity tests inject the oracle's)
         self.rts_uniform_override: Optional[Tensor] = None
         self.last_logits: Optional[Tensor] = None
+        #: seed of the multiplicative gate-input jitter of the last forward (0 = none); fixed value for tests
+        self.last_jitter_seed: int = 0
+        self.jitter_seed_override: Optional[int] = None
 
     def _set_ep_group(self, ep_group):
         self.ep_group = ep_group
 
-    def logits(self, x: Tensor) -> Tensor:
-        lg = ops.gate_logits(x, self.wg.weight.detach())
+    def logits(self, x: Tensor, jitter_seed: int = 0) -> Tensor:
+        lg = ops.gate_logits(x, self.wg.weight.detach(), jitter_seed)
         # upstream 0.9.5 calls self.wg(input) so forward hooks fire; 0.17.5 uses F.linear and they do not.
         # The reference's gating-logit capture (moellava/utils.py:38-46) relies on them: fire them by hand.
         if self.wg._forward_hooks:
@@ -78,15 +81,18 @@ class TopKGate(nn.Module):
     def forward(self, x: Tensor, used_token: Optional[Tensor] = None) -> ops.Routing:
         """Returns the index-form routing (upstream returns dense combine/dispatch masks; nothing in the
         reference tree calls the gate directly)."""
-        # upstream applies a noisy-gate policy only while training: 'Jitter' multiplies the gate input when
-        # `self.training`, and top1gating is handed `noisy_gate_policy if self.training else None`
+        # upstream applies a noisy-gate policy only while training: 'Jitter' multiplies the fp32 gate input by
+        # U(1 - 1e-2, 1 + 1e-2) when `self.training` (multiplicative_jitter), and top1gating is handed
+        # `noisy_gate_policy if self.training else None`.  The factors are generated inside the gate kernel from one
+        # seed (torch's CPU generator); the backward kernels regenerate them from the same seed.
+        jseed = 0
         if self.noisy_gate_policy == "Jitter" and self.training:
-            raise NotImplementedError("noisy_gate_policy='Jitter' (multiplicative jitter of the gate input while "
-                                      "training) is not implemented; the reference never sets it")
+            jseed = self.jitter_seed_override if self.jitter_seed_override is not None else _fresh_seed()
+        self.__dict__["last_jitter_seed"] = jseed
         if self.k == 2:
             used_token = None   # upstream top2gating takes no used_token: TopKGate.forward drops it for k = 2
                                 # (RePaMoE.forward passes *args through blindly, llava_stablelm_moe.py:709)
-        lg = self.logits(x)
+        lg = self.logits(x, jseed)
         self.__dict__["last_logits"] = lg   # kept for the backward pass (plain attribute, fast path)
         S, E = lg.shape
         if self.k == 1:
@@ -286,8 +292,8 @@ class MOELayer(nn.Module):
         if t is not None:
             t.mark("combine_end")
         if save:
-            saved.update(x=x, y=y, r=r, logits=self.gate.last_logits, act=act, w1=w1, w2=w2, ng=ng,
-                         has_b1=b1 is not None, has_b2=b2 is not None)
+            saved.update(x=x, y=y, r=r, logits=self.gate.last_logits, jseed=self.gate.last_jitter_seed, act=act, w1=w1,
+                         w2=w2, ng=ng, has_b1=b1 is not None, has_b2=b2 is not None)
         return out.reshape(x_in.shape), r.l_aux, saved
 
     def _backward(self, saved, dout: Tensor, dl_aux: Optional[Tensor]):
@@ -306,8 +312,8 @@ class MOELayer(nn.Module):
                 saved["act"], saved["a"], None, 0, saved["w1"], saved["w2"], saved["ab"], saved["h"], dy_recv,
                 saved["offs"], plan["n_recv"], saved["has_b1"], saved["has_b2"], saved["ng"])
             da_rows = self._exchange_rows_chunked(da_recv, r, plan, to_experts=False)
-        dlogits, dwg = ops.gate_bwd(x, saved["logits"], r, dweight, dl_aux)
-        dx = ops.dispatch_bwd(da_rows, r, dlogits, self.gate.wg.weight.detach(), S, M)
+        dlogits, dwg = ops.gate_bwd(x, saved["logits"], r, dweight, dl_aux, saved["jseed"])
+        dx = ops.dispatch_bwd(da_rows, r, dlogits, self.gate.wg.weight.detach(), S, M, saved["jseed"])
         return dx, dwg, dw1, db1, dw2, db2
 
     # ------------------------------------------------------------------------------------------

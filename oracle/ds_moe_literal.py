@@ -120,7 +120,7 @@ def top1gating_dense(logits: Tensor, capacity_factor: float, min_capacity: int,
                      ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """Upstream ``top1gating`` (SURVEY 8(a) footnote / 8(f) row f4).  ``noise`` is the
     Gumbel sample of noisy_gate_policy 'RSample' (the expert is then argmax(logits + noise)
-    instead of argmax(gates)); 'Jitter' acts on the gate INPUT and is not restated.
+    instead of argmax(gates)); 'Jitter' acts on the gate INPUT and is restated in TopKGateRef.forward.
     Without ``use_rts`` upstream's topk runs over a 0/1 column, so which C member tokens
     survive is whatever torch.topk does with ties (unspecified); this restatement then
     keeps the FIRST C member tokens in token order, the rule the kernels implement.  With ``use_rts`` upstream draws U(0,1) noise per (token, expert) and
@@ -182,12 +182,22 @@ class TopKGateRef(nn.Module):
         # injected randomness (oracle only): [S,E] tensors or None
         self.noise: Optional[Tensor] = None
         self.rts_uniform: Optional[Tensor] = None
+        #: [S,M] fp32 factors of noisy_gate_policy 'Jitter' (upstream draws Uniform(1 - 1e-2, 1 + 1e-2).rsample(x.shape)
+        #: inside multiplicative_jitter; the oracle takes the sample from outside, like its other randomness)
+        self.jitter: Optional[Tensor] = None
         self.last_logits: Optional[Tensor] = None
         #: oracle-only: use these fp32 logits instead of the CPU GEMV ("given fp32 gate logits" parity contract)
         self.logits_override: Optional[Tensor] = None
 
     def forward(self, x: Tensor, used_token: Optional[Tensor] = None):
-        logits = F.linear(x.float(), self.wg.weight.float())
+        input_fp32 = x.float()
+        # upstream TopKGate.forward: `if self.noisy_gate_policy == 'Jitter' and self.training:
+        #     input_fp32 = multiplicative_jitter(input_fp32, device=input.device)`  (= x * uniform sample)
+        if self.noisy_gate_policy == "Jitter" and self.training:
+            if self.jitter is None:
+                raise ValueError("oracle needs gate.jitter injected for noisy_gate_policy='Jitter' in training")
+            input_fp32 = input_fp32 * self.jitter.reshape(input_fp32.shape)
+        logits = F.linear(input_fp32, self.wg.weight.float())
         if self.logits_override is not None:
             assert self.logits_override.shape == logits.shape
             # value of the override, gradient of the linear (backward parity runs keep the graph)

@@ -23,7 +23,7 @@ def _install_cpu_stand_ins():
     from moe_llava_amd import ops
     from oracle import ds_moe_index as ix
 
-    def gate_logits(x, wg):
+    def gate_logits(x, wg, jitter_seed=0):
         return F.linear(x.float(), wg.float())
 
     def routing_top2(logits, capacity, noise=None, drop_tokens=True, noise_seed=0):
@@ -179,7 +179,7 @@ def _install_cpu_stand_ins():
             dweight[on, j] = (dout[on].float() * y[pos[on, j]].float()).sum(1)
         return dy, dweight
 
-    def gate_bwd(x, logits, r, dweight, dl_aux):
+    def gate_bwd(x, logits, r, dweight, dl_aux, jitter_seed=0):
         S, E = logits.shape
         lg = logits.clone().requires_grad_(True)
         with torch.enable_grad():
@@ -193,7 +193,7 @@ def _install_cpu_stand_ins():
             tot.backward()
         return lg.grad, lg.grad.t() @ x.float()
 
-    def dispatch_bwd(da_rows, r, dlogits, wg_weight, S, M):
+    def dispatch_bwd(da_rows, r, dlogits, wg_weight, S, M, jitter_seed=0):
         dx = torch.zeros(S, M)
         pos = _pos(r)
         for j in range(r.expert_idx.shape[1]):

@@ -77,6 +77,46 @@ def test_block_gradients_vs_oracle_autograd(kind, M, I, E, shape, cf, noisy):
     assert n == len(rp)
 
 
+@pytest.mark.parametrize("kind,M,I,E,shape,cf", [("stablelm", 128, 320, 4, (3, 111), 1.5), ("phi", 64, 256, 8, (1, 257), 1.0),
+                                              ("qwen", 2048, 128, 4, (1, 70), 2.0)])
+def test_jitter_policy_gradients_vs_oracle_autograd(kind, M, I, E, shape, cf):
+    """noisy_gate_policy='Jitter' in training: forward and every gradient against autograd over the literal oracle that is
+    given the SAME factors (read back from the seed with ops.gate_jitter) -- the gate input is x.float() * factors, so dwg
+    sees the jittered input and the gate's share of dx is scaled by the factors."""
+    from moe_llava_amd import ops
+    ref, mine, x = _build_pair(kind, M, I, E, shape, cf, seed=21, noisy=False)
+    S = x.numel() // M
+    for m in (ref, mine):
+        m.deepspeed_moe.gate.noisy_gate_policy = "Jitter"
+    seed = 0x0bad_cafe_1234_5677
+    mine.deepspeed_moe.gate.jitter_seed_override = seed
+    ref.deepspeed_moe.gate.jitter = ops.gate_jitter(seed, S, M, DEV).cpu()
+    g = torch.Generator().manual_seed(22)
+    R = torch.randn(x.shape, generator=g).to(torch.bfloat16)
+    xg = x.to(DEV).requires_grad_(True)
+    out, l_aux, _ = mine(xg)
+    assert mine.deepspeed_moe.gate.last_jitter_seed == seed
+    ((out.float() * R.to(DEV).float()).sum() + 0.3 * l_aux).backward()
+    torch.cuda.synchronize()
+    lg_mine = mine.deepspeed_moe.gate.last_logits.cpu()
+    xr = x.clone().requires_grad_(True)
+    # first the oracle's own jittered GEMV against the kernel's logits, then the kernel's logits injected for the routing
+    r_out, r_laux, _ = ref(xr)
+    lg_ref = ref.deepspeed_moe.gate.last_logits
+    assert float((lg_mine - lg_ref).abs().max()) <= 1e-4 * max(1.0, float(lg_ref.abs().max()))
+    ref.deepspeed_moe.gate.logits_override = lg_mine
+    xr = x.clone().requires_grad_(True)
+    r_out, r_laux, _ = ref(xr)
+    ((r_out.float() * R.float()).sum() + 0.3 * r_laux).backward()
+    tag = f"jitter {kind} M{M}"
+    _cmp(tag + " out", out, r_out, tol=1e-2)
+    _cmp(tag + " dx", xg.grad, xr.grad)
+    _cmp(tag + " dwg", mine.deepspeed_moe.gate.wg.weight.grad, ref.deepspeed_moe.gate.wg.weight.grad)
+    rp = dict(ref.deepspeed_moe.experts.named_parameters())
+    for name, p in mine.deepspeed_moe.experts.named_parameters():
+        _cmp(f"{tag} {name}", p.grad, rp[name].grad)
+
+
 def test_training_forward_equals_inference_forward():
     """The training path (plain fc1 + activation kernel, pre-activations kept) gives bit-identical outputs to the
     fused-epilogue inference path."""

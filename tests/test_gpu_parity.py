@@ -259,11 +259,31 @@ def test_top2_ignores_used_token_and_eval_ignores_jitter():
         b, lb, cb = mine(x.to(DEV), used)
         mine.deepspeed_moe.gate.noisy_gate_policy = "Jitter"
         c, lc, cc = mine(x.to(DEV))                           # eval: the policy is ignored
-        mine.train()
-        with pytest.raises(NotImplementedError):
-            mine(x.to(DEV))
     assert torch.equal(a, b) and torch.equal(ca, cb) and float(la) == float(lb)
     assert torch.equal(a, c) and torch.equal(ca, cc)
+    assert mine.deepspeed_moe.gate.last_jitter_seed == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,M,E", [(37, 64, 4), (300, 2048, 4), (129, 512, 16)])
+def test_gate_jitter_factors_and_logits(S, M, E):
+    """noisy_gate_policy='Jitter': the factors are U(1 - 1e-2, 1 + 1e-2) samples that depend on (seed, token, column)
+    only, and the gate kernel's logits are F.linear(x.float() * factors, wg) (upstream multiplicative_jitter)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(S + M)
+    x = torch.randn(S, M, generator=g).to(torch.bfloat16)
+    wg = torch.randn(E, M, generator=g) * 0.1
+    seed = 0x1234_5678_9abc_def1
+    J = ops.gate_jitter(seed, S, M, DEV).cpu()
+    assert float(J.min()) >= 1.0 - 1e-2 and float(J.max()) <= 1.0 + 1e-2
+    assert abs(float(J.mean()) - 1.0) < 2e-3 and float(J.std()) > 4e-3          # uniform on a 2e-2 interval: std 5.8e-3
+    assert torch.equal(J[: S // 2], ops.gate_jitter(seed, S // 2, M, DEV).cpu())  # no dependence on the launch shape
+    assert not torch.equal(J, ops.gate_jitter(seed + 1, S, M, DEV).cpu())
+    lg = ops.gate_logits(x.to(DEV), wg.to(DEV), jitter_seed=seed).cpu()
+    ref = (x.double() * J.double()) @ wg.double().T
+    plain = ops.gate_logits(x.to(DEV), wg.to(DEV)).cpu()
+    assert float((lg.double() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((plain.double() - ref).abs().max()) > 10 * float((lg.double() - ref).abs().max())
 
 
 def test_eval_mode_uses_eval_capacity_and_s1_decode():

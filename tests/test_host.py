@@ -33,19 +33,19 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.moe_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.moe_abi_version() == _lib.ABI_VERSION == 7
     assert lib.moe_routing_workspace_bytes(22528, 4) > 0
 
 
 def test_argument_validation_happens_before_any_launch():
     """Negative return codes = nothing launched; safe to call without a GPU."""
     lib = _lib.load()
-    assert lib.moe_gate_logits_fwd(None, None, 0, None, 4, 64, 4, 0, None) == -1
+    assert lib.moe_gate_logits_fwd(None, None, 0, None, 4, 64, 4, 0, 0, None) == -1
     assert b"null" in lib.moe_last_error()
-    assert lib.moe_gate_logits_fwd(16, 16, 0, 16, 4, 60, 4, 0, None) == -2       # M % 8
-    assert lib.moe_gate_logits_fwd(8, 16, 0, 16, 4, 64, 4, 1, None) == -3        # alignment
-    assert lib.moe_gate_logits_fwd(16, 16, 1, 16, 4, 64, 4, 1, None) == -1       # bf16 gate weight with fp16 activations
-    assert lib.moe_gate_logits_fwd(16, 16, 0, 16, 4, 64, 4, 2, None) == -1       # unknown dtype
+    assert lib.moe_gate_logits_fwd(16, 16, 0, 16, 4, 60, 4, 0, 0, None) == -2       # M % 8
+    assert lib.moe_gate_logits_fwd(8, 16, 0, 16, 4, 64, 4, 1, 0, None) == -3        # alignment
+    assert lib.moe_gate_logits_fwd(16, 16, 1, 16, 4, 64, 4, 1, 0, None) == -1       # bf16 gate weight with fp16 activations
+    assert lib.moe_gate_logits_fwd(16, 16, 0, 16, 4, 64, 4, 2, 0, None) == -1       # unknown dtype
     assert lib.moe_routing_top2_fwd(16, None, 0, 4, 1, 2, 1, 16, 16, 16, 16, 16, 16, 16, 16, 16, 1 << 20, None) == -2  # E<2
     assert lib.moe_routing_top2_fwd(16, None, 0, 4, 4, 2, 1, 16, 16, 16, 16, 16, 16, 16, 16, 16, 8, None) == -4  # workspace
     assert lib.moe_expert_ffn_fwd(7, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 64, -1, 16, 16, 0, None) == -1
