@@ -264,6 +264,22 @@ def cpu_baseline(state, budget_s: float = 12.0, gpu_moe=None, device=None):
             "seconds": t}
 
 
+def self_launch(n: int) -> int:
+    """Run this script as n ranks on this node (one per GPU) under torch.distributed.run; returns the exit code.
+    Called before anything initialises the GPU in this process, which stays a pure parent (no exec of a GPU process)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 8) // n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,13 +293,14 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs object")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU (no HIP call, no library load) and never
+        # will -- it starts the N ranks as children of torch.distributed.run, waits, and exits with their code
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+    args.gpus = world
     import torch.distributed as dist
     # BENCH_REHEARSAL=1: several ranks share cuda:0 over a gloo group (the all-to-all payload is staged through the
     # host) -- only to rehearse the N > 1 code path on a one-GPU box; the numbers it prints are meaningless.
@@ -351,6 +368,14 @@ def main():
     else:
         # rows received by this rank's experts per grouped-FFN launch (the exchange is pipelined in chunks)
         rows_local = moe.deepspeed_moe.last_ffn_rows // max(1, moe.deepspeed_moe.last_ffn_launches)
+    # what every rank saw: the communicator's world size and the GEMM rows of its experts' launches (N > 1: shows in the
+    # record that N ranks met and how the rows were spread)
+    ranks_seen, rows_per_gpu = 1, [int(moe.deepspeed_moe.last_ffn_rows) if ep > 1 else int(r.expert_offsets[-1])]
+    if world > 1:
+        ranks_seen = dist.get_world_size()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rows_per_gpu[0])
+        rows_per_gpu = [int(v) for v in gathered]
     fc1_avg = statistics.mean(fc1_ms) if fc1_ms else None
     n1 = (2 * I) if cfg["kind"] != "phi" else I
     roofline = None
@@ -432,7 +457,8 @@ def main():
             "metric": f"MoE-layer tokens/sec (top-2, {E} experts, {cfg['kind']} block)",
             "value": world * S * args.steps / elapsed,
             "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "n_gpus": world, "ranks_seen": ranks_seen, "rows_per_gpu": rows_per_gpu,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic" + (" (REHEARSAL: ranks share one GPU over gloo, timing meaningless)" if rehearsal else ""),
             "config": {"workload": f"{cfg['tag']}: d={M}, expert width {I} ({cfg['kind']}), {E} experts top-{TOPK}, capacity "

@@ -88,6 +88,8 @@ class TopKGate(nn.Module):
         jseed = 0
         if self.noisy_gate_policy == "Jitter" and self.training:
             jseed = self.jitter_seed_override if self.jitter_seed_override is not None else _fresh_seed()
+            if jseed == 0:
+                raise ValueError("jitter_seed_override = 0 would switch the jitter off (0 means 'no jitter' in the C ABI)")
         self.__dict__["last_jitter_seed"] = jseed
         if self.k == 2:
             used_token = None   # upstream top2gating takes no used_token: TopKGate.forward drops it for k = 2
@@ -342,7 +344,11 @@ class MOELayer(nn.Module):
         # every rank learns every rank's kept counts: [ep(src), E]; the one host sync of the call
         k = _all_gather_counts(r.kept_counts, ep, self.ep_group).numpy().astype(np.int64)
         n_send, n_recv = int(k[me].sum()), int(k[:, me * El:(me + 1) * El].sum())
-        C = _ep_chunks(n_send, n_recv, M, ep, self._ep_bandwidth(x))
+        # The chunk count must be the SAME on every rank of the group (each chunk is one all_to_all_single on every rank):
+        # it is derived only from the count matrix, which every rank holds, and from the group's agreed bandwidth.
+        sends = k.sum(1)                                             # [ep] rows every rank sends
+        recvs = k.reshape(ep, ep, El).sum((0, 2))                    # [ep] rows every rank receives
+        C = _ep_chunks(int(min(sends.min(), recvs.min())), int(sends.max()), M, ep, _ep_bandwidth(self.ep_group, ep, x))
         edges = (k[:, :, None] * np.arange(C + 1, dtype=np.int64)) // C      # [src, e, C+1]
         cnt = edges[:, :, 1:] - edges[:, :, :-1]                             # [src, e, c]
         send_cnt = cnt[me].reshape(ep, El, C).sum(1)                         # [dest, c]
@@ -438,48 +444,70 @@ class MOELayer(nn.Module):
         ops.ep_chunk_rows(cm, None, 0, r.expert_offsets, C, True, n_send, out=out)
         return out
 
-    def _ep_bandwidth(self, x: Tensor) -> float:
-        """Per-peer all-to-all bandwidth of the EP group in GB/s, measured once (first expert-parallel forward, which
-        every rank of the group enters together): 8 MiB to every peer, second of two runs timed.  Sizes the chunking
-        of the exchange (``_ep_chunks``).  Not measurable on a gloo group or a single rank: returns 0 (= unknown)."""
-        bw = self.__dict__.get("_ep_bw")
-        if bw is not None:
-            return bw
-        import torch.distributed as dist
-        bw = 0.0
-        env = os.environ.get("MOE_EP_BW_GBS")
-        if env:
-            bw = float(env)
-        elif x.is_cuda and self.ep_size > 1 and not _group_is_gloo(self.ep_group):
-            per = 8 << 20
-            a = torch.empty(self.ep_size * per, dtype=torch.uint8, device=x.device)
-            b = torch.empty_like(a)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            for i in range(2):
-                ev[0].record()
-                dist.all_to_all_single(b, a, group=self.ep_group)
-                ev[1].record()
-            torch.cuda.synchronize(x.device)
-            ms = ev[0].elapsed_time(ev[1])
-            if ms > 0:
-                bw = per / (ms * 1e-3) / 1e9          # bytes to ONE peer / time of the whole exchange (links run in parallel)
-        self.__dict__["_ep_bw"] = bw
+
+_EP_BW = {}          # process group -> per-peer all-to-all bandwidth in GB/s, agreed by all its ranks
+
+
+def _ep_bandwidth(group, ep: int, x: Tensor) -> float:
+    """Per-peer all-to-all bandwidth of an EP group in GB/s: measured ONCE per process group (not per layer) on the first
+    expert-parallel forward, which every rank of the group enters together, then agreed (MIN over the ranks), so that
+    every rank sizes the chunking of the exchange (``_ep_chunks``) from the same number.  Every rank of the group runs
+    the same collectives here whatever its environment: 8 MiB to every peer twice (second run timed), then one
+    all-reduce that also carries ``MOE_EP_BW_GBS`` -- an override set on ANY rank is adopted by all.  A gloo group or a
+    single rank cannot be measured: 0 (= unknown) unless overridden."""
+    key = group
+    bw = _EP_BW.get(key)
+    if bw is not None:
         return bw
+    import torch.distributed as dist
+    env = os.environ.get("MOE_EP_BW_GBS")
+    env_bw = float(env) if env else float("inf")
+    measured = float("inf")
+    gloo = _group_is_gloo(group)
+    if x.is_cuda and ep > 1 and not gloo:
+        per = 8 << 20
+        a = torch.empty(ep * per, dtype=torch.uint8, device=x.device)
+        b = torch.empty_like(a)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for i in range(2):
+            ev[0].record()
+            dist.all_to_all_single(b, a, group=group)
+            ev[1].record()
+        torch.cuda.synchronize(x.device)
+        ms = ev[0].elapsed_time(ev[1])
+        if ms > 0:
+            measured = per / (ms * 1e-3) / 1e9      # bytes to ONE peer / time of the whole exchange (links run in parallel)
+    if ep > 1 and group is not None:
+        t = torch.tensor([measured, env_bw], dtype=torch.float64, device=x.device if (x.is_cuda and not gloo) else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        measured, env_bw = float(t[0]), float(t[1])
+    bw = env_bw if math.isfinite(env_bw) else (measured if math.isfinite(measured) else 0.0)
+    _EP_BW[key] = bw
+    return bw
 
 
-def _ep_chunks(n_send: int, n_recv: int, M: int = 0, ep: int = 1, bw_gbs: float = 0.0) -> int:
-    """Chunks the expert-parallel exchange is pipelined in (MOE_EP_CHUNKS overrides; 1 = one exchange each way).
+EP_MAX_CHUNKS = 64   # what moe_ep_chunk_rows_fwd accepts
+
+
+def _ep_chunks(rows_min: int, send_max: int, M: int = 0, ep: int = 1, bw_gbs: float = 0.0) -> int:
+    """Chunks the expert-parallel exchange is pipelined in: 1-4 by the rule below, ``MOE_EP_CHUNKS`` forces a count of up
+    to 64 (1 = one exchange each way).  Every argument must be identical on all ranks of the group: ``rows_min`` = the
+    fewest rows any rank sends or receives, ``send_max`` = the most rows any rank sends (both from the all-gathered
+    count matrix), ``bw_gbs`` the group's agreed per-peer bandwidth.
     Chunking costs ~0.1 ms per extra chunk in launch tails (measured) and hides wire time: it is worth it when
     the bytes to one peer take longer than that on the measured per-peer bandwidth, and a chunk still holds >= 4096
     rows (a few rounds of 256-row tiles).  With no measurement (bw_gbs == 0) the round-1 rule stands: 4 chunks from
     16 384 rows."""
     env = os.environ.get("MOE_EP_CHUNKS")
     if env:
-        return max(1, int(env))
-    rows = min(n_send, n_recv)
+        c = int(env)
+        if not 1 <= c <= EP_MAX_CHUNKS:
+            raise ValueError(f"MOE_EP_CHUNKS={env}: must be between 1 and {EP_MAX_CHUNKS}")
+        return c
+    rows = rows_min
     if bw_gbs <= 0.0:
         return 4 if rows >= 16384 else 1
-    wire_ms = (n_send * M * 2.0 / max(ep, 1)) / (bw_gbs * 1e9) * 1e3        # one direction, one peer link
+    wire_ms = (send_max * M * 2.0 / max(ep, 1)) / (bw_gbs * 1e9) * 1e3       # one direction, one peer link
     if rows < 8192 or wire_ms < 0.15:
         return 1
     return int(max(2, min(4, rows // 4096, round(wire_ms / 0.15))))

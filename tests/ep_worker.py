@@ -274,6 +274,54 @@ def run_single_rank_rccl(rank: int, port: int, result_dir: str):
         dist.destroy_process_group()
 
 
+def run_chunk_agreement(rank: int, world: int, port: int, result_dir: str):
+    """The DEFAULT chunk rule (MOE_EP_CHUNKS unset) with per-rank token counts on either side of its thresholds, and a
+    bandwidth override present on rank 0 only: every rank must issue the same number of exchanges (a rank that chose
+    another count would hang the group or mis-slice the rows), and the result must not depend on the count."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("MOE_EP_CHUNKS", None)
+    os.environ.pop("MOE_EP_BW_GBS", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _install_cpu_stand_ins()
+        from moe_llava_amd import sharded_moe
+        M, I, E, ep = 64, 64, 4, 2
+        full, part = _build(M, I, E, ep, seed=11, kind="stablelm")
+        el = E // ep
+        for le, mod in enumerate(part.deepspeed_moe.experts.deepspeed_experts):
+            mod.load_state_dict(full.deepspeed_moe.experts.deepspeed_experts[(rank % ep) * el + le].state_dict())
+        part.deepspeed_moe.gate.wg.weight.data = full.deepspeed_moe.gate.wg.weight.data.clone()
+        full, part = full.eval(), part.eval()          # eval capacity 2.0: nothing dropped, rows = 2 S
+        part.set_deepspeed_parallelism()
+        layer = part.deepspeed_moe
+        # rank 0 sends 2 * 9000 = 18000 rows (>= the 16384-row threshold of the no-measurement rule), rank 1 2 * 7000
+        S = 9000 if rank == 0 else 7000
+        x = torch.randn(1, S, M, generator=torch.Generator().manual_seed(40 + rank)).to(torch.bfloat16)
+        seen = []
+        for phase in ("no bandwidth known", "override on rank 0 only"):
+            if phase.startswith("override"):
+                sharded_moe._EP_BW.clear()             # as on a fresh process group: the probe runs again, on every rank
+                if rank == 0:
+                    os.environ["MOE_EP_BW_GBS"] = "0.5"   # slow links: the rule wants several chunks
+            with torch.no_grad():
+                want, _, c_ref = full(x)
+                got, _, cnt = part(x)
+            launches = [None] * world
+            dist.all_gather_object(launches, int(layer.last_ffn_launches))
+            assert len(set(launches)) == 1, (phase, launches)
+            assert torch.equal(cnt, c_ref)
+            assert torch.allclose(got.float(), want.float(), rtol=1e-2, atol=1e-3)
+            seen.append(launches[0])
+        assert seen[0] == 1, seen                      # min over ranks of (send, recv) is below 16384 rows
+        assert seen[1] > 1, seen                       # rank 0's override was adopted by rank 1 too
+        with open(os.path.join(result_dir, f"ok_{rank}"), "w") as f:
+            f.write(f"launches={seen}\n")
+    finally:
+        os.environ.pop("MOE_EP_BW_GBS", None)
+        dist.destroy_process_group()
+
+
 def run(rank: int, world: int, port: int, mode: str, kind: str, result_dir: str):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

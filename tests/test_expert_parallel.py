@@ -42,6 +42,14 @@ def test_expert_parallel_two_groups_of_two_cpu_gloo():
     assert len(info) == 4
 
 
+def test_default_chunk_count_is_the_same_on_every_rank_cpu_gloo():
+    """MOE_EP_CHUNKS unset, skewed per-rank token counts around the rule's thresholds, a bandwidth
+    override on one rank only -- the ranks must agree on the number of exchanges."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(ep_worker.run_chunk_agreement, args=(2, _free_port(), d), nprocs=2, join=True)
+        assert sorted(os.listdir(d)) == ["ok_0", "ok_1"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["stablelm", "phi"])
 def test_expert_parallel_two_ranks_one_gpu(kind):
