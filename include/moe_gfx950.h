@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MOE_ABI_VERSION 7
+#define MOE_ABI_VERSION 8
 
 /* Element type of the 16-bit activations, expert weights and biases of a forward call (`dtype` arguments below).
  * bf16 is what the reference trains and serves with (--bf16); fp16 is what its inference loader builds the model in
@@ -183,12 +183,32 @@ int moe_routing_top1_fwd(const float *logits, const float *noise, uint64_t noise
  *   h_ws         workspace [max_rows, I] bf16
  *   y            output    [max_rows, M] bf16: y[p] = expert(row p), rounded to bf16 per Linear as the
  *                reference's nn.Linear modules do
- * M % 64 == 0, I % 64 == 0, all pointers 16-byte aligned.  Two launches.
+ *   splitk_ws    (ABI v8) NULL, or a device workspace of splitk_ws_bytes >= moe_splitk_workspace_bytes() for the
+ *                split-K tail of the two launches (below); its contents mean nothing between calls, but two calls that
+ *                may run at the same time (different streams) need a workspace each
+ * M % 64 == 0, I % 64 == 0, all pointers 16-byte aligned.  Two launches (four with a split-K workspace).
  */
 int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                        const void *w1, const void *b1, const void *w2, const void *b2,
                        const int32_t *group_offsets, int G, int n_experts_local, int max_rows,
-                       int M, int I, int n_gated, void *h_ws, void *y, int dtype, void *stream);
+                       int M, int I, int n_gated, void *h_ws, void *y, void *splitk_ws, size_t splitk_ws_bytes,
+                       int dtype, void *stream);
+
+/* Split-K tail of the grouped GEMM launches (ABI v8; no counterpart in the reference, whose expert GEMMs are cuBLAS
+ * calls).  A launch is a list of tiles that each XCD's 32 CUs work through in rounds; the last round of an XCD is
+ * usually partial (config 3's fc2: 4.3 rounds run as 5).  Given a workspace, the Rm < 32 tiles of that round are cut
+ * along K into floor(32 / Rm) pieces (at most MOE_SPLITK, default 8; a piece is at least 4 K slices of 64) that leave
+ * their fp32 accumulators in the workspace, and a fix-up launch right behind adds each tile's pieces IN K ORDER and runs
+ * the epilogue: no atomics, results bit-identical from call to call.  A split tile differs from a whole one only through
+ * the fp32 summation order over K, so two launches that cut their lists differently (another row count, another
+ * chunking of the expert-parallel exchange) may differ in the last bit of a 16-bit output; NULL keeps every tile whole.
+ * moe_splitk_workspace_bytes(): one 256 x 256 fp32 tile per CU = 64 MiB, enough for every tile shape. */
+size_t moe_splitk_workspace_bytes(void);
+
+/* moe_reload_knobs: the library reads its diagnostic environment knobs (MOE_GEMM_TILE, MOE_GEMM_ORDER, MOE_NO_PERSIST,
+ * MOE_NO_SKINNY, MOE_NO_GATE_ROUTE_FUSION, MOE_SKINNY_NW, MOE_SKINNY_KS, MOE_SPLITK) once, at first use; a test or
+ * tuning tool that changes one of them afterwards calls this to have them read again. */
+void moe_reload_knobs(void);
 
 /* epilogues of moe_grouped_gemm_fwd */
 #define MOE_EPI_PLAIN    0 /* out = bf16(acc + bias)                                  (fc2 / down_proj / c_proj) */
@@ -201,11 +221,11 @@ int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gathe
  * (stablelm/modeling_stablelm_epoch.py:167-168, phi/modeling_phi.py:211-215, qwen/modeling_qwen.py:601-606).
  *   w    [n_experts_local, N (or 2N for SWIGLU), K] bf16;  bias [n_experts_local, N (or 2N)] bf16 or NULL
  *   n_gated: MOE_EPI_SWIGLU only, as in moe_expert_ffn_fwd (-1 or N = every column gated); ignored otherwise
- * K % 64 == 0, N % 4 == 0, lda >= K, ldo >= N.  One launch. */
+ * K % 64 == 0, N % 4 == 0, lda >= K, ldo >= N.  One launch (two with a split-K workspace, see above). */
 int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                          const void *w, const void *bias, const int32_t *group_offsets, int G,
                          int n_experts_local, int max_rows, int K, int N, int n_gated, void *out, int64_t ldo,
-                         int dtype, void *stream);
+                         void *splitk_ws, size_t splitk_ws_bytes, int dtype, void *stream);
 
 /* moe_gather_rows_fwd: dst[p] = src[gather[p] >> gather_shift] for p < *n_rows_dev (device int32),
  * rows of M 16-bit elements (a copy: bf16 and fp16 alike, hence no dtype argument).  Builds the expert-sorted send buffer of the expert-parallel all-to-all
@@ -243,7 +263,8 @@ int moe_block_top2_fwd(const void *x, const void *wg, int wg_dtype, float *logit
                        int n_gated, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                        int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
                        void *routing_ws, size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2,
-                       const void *b2, void *h_ws, void *y, void *out, int dtype, void *stream);
+                       const void *b2, void *h_ws, void *y, void *out, void *splitk_ws, size_t splitk_ws_bytes,
+                       int dtype, void *stream);
 
 /* moe_block_top2_fwd_dseed: moe_block_top2_fwd with the routing of moe_routing_top2_fwd_dseed (seed in device memory,
  * advanced by the kernel): the form a HIP graph of a decode step captures.  S <= 4096, E <= 16. */
@@ -252,7 +273,8 @@ int moe_block_top2_fwd_dseed(const void *x, const void *wg, int wg_dtype, float 
                              int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                              int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
                              void *routing_ws, size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2,
-                             const void *b2, void *h_ws, void *y, void *out, int dtype, void *stream);
+                             const void *b2, void *h_ws, void *y, void *out, void *splitk_ws, size_t splitk_ws_bytes,
+                             int dtype, void *stream);
 
 /* ---- backward ---------------------------------------------------------------
  * Upstream has no hand-written backward: torch autograd differentiates top2gating, the two einsums, _AllToAll
@@ -267,7 +289,8 @@ int moe_block_top2_fwd_dseed(const void *x, const void *wg, int wg_dtype, float 
 int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                              const void *w1, const void *b1, const void *w2, const void *b2,
                              const int32_t *group_offsets, int G, int n_experts_local, int max_rows,
-                             int M, int I, int n_gated, void *ab, void *h, void *y, void *stream);
+                             int M, int I, int n_gated, void *ab, void *h, void *y, void *splitk_ws,
+                             size_t splitk_ws_bytes, void *stream);
 
 size_t moe_expert_ffn_bwd_workspace_bytes(int act, int G, int n_experts_local, int max_rows, int M, int I);
 

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # MOE_GFX950_LIB points the loader at another build of the same ABI (kernel A/B experiments, tools/variants)
 LIB_PATH = os.environ.get("MOE_GFX950_LIB") or os.path.join(_PKG, "libmoe_gfx950.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # (name, restype, argtypes) -- must mirror include/moe_gfx950.h exactly
 _SIGNATURES = [
@@ -36,12 +36,14 @@ _SIGNATURES = [
     ("moe_routing_top1_fwd", c_int,
      [c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("moe_splitk_workspace_bytes", c_size_t, []),
+    ("moe_reload_knobs", None, []),
     ("moe_expert_ffn_fwd", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     ("moe_grouped_gemm_fwd", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-      c_int, c_void_p, c_int64, c_int, c_void_p]),
+      c_int, c_void_p, c_int64, c_void_p, c_size_t, c_int, c_void_p]),
     ("moe_gather_rows_fwd", c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     ("moe_ep_chunk_rows_fwd", c_int,
      [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -50,15 +52,15 @@ _SIGNATURES = [
     ("moe_block_top2_fwd", c_int,
      [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_uint64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     ("moe_block_top2_fwd_dseed", c_int,
      [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     # ---- backward ----
     ("moe_expert_ffn_fwd_train", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("moe_expert_ffn_bwd_workspace_bytes", c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     ("moe_expert_ffn_bwd", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -12,12 +12,12 @@ static int block_top2(const void *x, int dtype, const void *wg, int wg_dtype, fl
                       int n_gated, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                       int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux, void *routing_ws,
                       size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2, const void *b2, void *h_ws,
-                      void *y, void *out, void *stream) {
+                      void *y, void *out, void *splitk_ws, size_t splitk_ws_bytes, void *stream) {
     if (S < 1) return fail(MOE_ERR_SHAPE, "moe_block_top2_fwd: need S >= 1");
     const long long cap_rows = (long long)E * capacity;
     const int max_rows = drop_tokens ? (int)(2ll * S < cap_rows ? 2ll * S : cap_rows) : 2 * S;
     int rc;
-    if (gate_route_small_applies(S, E) && !getenv("MOE_NO_GATE_ROUTE_FUSION")) {
+    if (gate_route_small_applies(S, E) && !knobs().no_gate_route_fusion) {
         // decode step: gate GEMV + routing in one launch (bit-identical logits and routing)
         rc = launch_gate_route_small(x, dtype, wg, wg_dtype, logits, noise, noise_seed, noise_seed_dev, S, M, E, capacity,
                                      drop_tokens, expert_idx, slot, weight, exp_counts, kept_counts, expert_offsets, perm,
@@ -36,7 +36,7 @@ static int block_top2(const void *x, int dtype, const void *wg, int wg_dtype, fl
     if (rc) return rc;
     if (max_rows > 0) {
         rc = moe_expert_ffn_fwd(act, x, M, perm, 1, w1, b1, w2, b2, expert_offsets, E, E, max_rows, M, I, n_gated, h_ws, y,
-                                dtype, stream);
+                                splitk_ws, splitk_ws_bytes, dtype, stream);
         if (rc) return rc;
     }
     return moe_combine_fwd(y, expert_idx, slot, weight, expert_offsets, S, M, 2, out, dtype, stream);
@@ -47,10 +47,11 @@ extern "C" int moe_block_top2_fwd(const void *x, const void *wg, int wg_dtype, f
                                   int n_gated, int32_t *expert_idx, int32_t *slot, float *weight, int64_t *exp_counts,
                                   int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm, float *l_aux,
                                   void *routing_ws, size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2,
-                                  const void *b2, void *h_ws, void *y, void *out, int dtype, void *stream) {
+                                  const void *b2, void *h_ws, void *y, void *out, void *splitk_ws, size_t splitk_ws_bytes,
+                                  int dtype, void *stream) {
     return block_top2(x, dtype, wg, wg_dtype, logits, noise, noise_seed, nullptr, S, M, E, I, act, capacity, drop_tokens, n_gated,
                       expert_idx, slot, weight, exp_counts, kept_counts, expert_offsets, perm, l_aux, routing_ws,
-                      routing_ws_bytes, w1, b1, w2, b2, h_ws, y, out, stream);
+                      routing_ws_bytes, w1, b1, w2, b2, h_ws, y, out, splitk_ws, splitk_ws_bytes, stream);
 }
 
 // The same with the Gumbel seed in device memory, read and advanced by the routing kernel: every launch argument is
@@ -61,9 +62,9 @@ extern "C" int moe_block_top2_fwd_dseed(const void *x, const void *wg, int wg_dt
                                         int64_t *exp_counts, int32_t *kept_counts, int32_t *expert_offsets, int32_t *perm,
                                         float *l_aux, void *routing_ws, size_t routing_ws_bytes, const void *w1,
                                         const void *b1, const void *w2, const void *b2, void *h_ws, void *y, void *out,
-                                        int dtype, void *stream) {
+                                        void *splitk_ws, size_t splitk_ws_bytes, int dtype, void *stream) {
     if (!noise_seed_dev) return fail(MOE_ERR_ARG, "moe_block_top2_fwd_dseed: null noise_seed_dev");
     return block_top2(x, dtype, wg, wg_dtype, logits, nullptr, 0, noise_seed_dev, S, M, E, I, act, capacity, drop_tokens, n_gated,
                       expert_idx, slot, weight, exp_counts, kept_counts, expert_offsets, perm, l_aux, routing_ws,
-                      routing_ws_bytes, w1, b1, w2, b2, h_ws, y, out, stream);
+                      routing_ws_bytes, w1, b1, w2, b2, h_ws, y, out, splitk_ws, splitk_ws_bytes, stream);
 }

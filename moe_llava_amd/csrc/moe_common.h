@@ -13,6 +13,19 @@ namespace moe {
 char *err_buf();
 int fail(int code, const char *fmt, ...);
 
+// Diagnostic / tuning knobs of the environment, read ONCE (first use; moe_reload_knobs() reads them again): a decode
+// step used to spend eight getenv() calls per forward.
+struct Knobs {
+    int tile_bm, tile_bnw;     // MOE_GEMM_TILE="bm,bnw": force a tile of the grouped GEMM (0 = the host rule)
+    int order;                 // MOE_GEMM_ORDER: 0 super-rows, 1 group-major, -1 = rule
+    bool no_persist;           // MOE_NO_PERSIST
+    bool no_skinny;            // MOE_NO_SKINNY: decode-size launches through the tiled kernel
+    bool no_gate_route_fusion; // MOE_NO_GATE_ROUTE_FUSION
+    int skinny_nw, skinny_ks;  // MOE_SKINNY_NW / MOE_SKINNY_KS (0 = rule)
+    int splitk;                // MOE_SPLITK: largest split factor of the split-K tail (0 or 1 = off; default 8)
+};
+const Knobs &knobs();
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -290,6 +303,7 @@ struct GemmParams {
     bf16_t *out;
     long long ldo;
     int K;
+    long long ldw;     // row stride of w in elements (= K for the packed nn.Linear layout)
     int N_out;         // output columns
     int b_row_offset;  // gated: W row of the first 'b' projection row (= I)
     int n_gated;       // gated: output columns >= n_gated bypass SiLU (RePaMLP mask); = N_out for plain SwiGLU
@@ -299,6 +313,8 @@ struct GemmParams {
     const bf16_t *aux;  // EPI_DSWIGLU / EPI_DGELU: pre-activations AB [rows, ld_aux]
     long long ld_aux;
     int dtype;          // DT_BF16 / DT_F16: element type of a, w, bias, out (16-bit raw in the pointers above)
+    float *splitk_ws;   // split-K tail (moe_gemm.hip): fp32 accumulators of the K pieces; NULL = no split
+    int splitk_max;     // largest split factor (<= 1: tiles are never split)
 };
 
 // Decode-size launches (moe_gemv.hip): every group has at most SKINNY_MAX_ROWS rows.

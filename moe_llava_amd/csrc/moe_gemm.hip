@@ -23,6 +23,7 @@
 namespace moe {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4v_t;
 
 constexpr int BK = 64;  // K slice per ring slot
 constexpr int NTHREADS = 512;
@@ -125,31 +126,66 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int DT, int EPI, int BM, int BNW>
-__global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmParams p) {
-    using T = Tile<EPI, BM, BNW>;
-    typedef Elt<DT> E;                    // element type of the operands and of the output (bf16 / fp16)
-    typedef typename E::frag_t bf16x8_t;  // 8 K-consecutive elements: one MFMA operand
-#ifdef GEMM_STAMPS
-    const unsigned long long st_entry = stamp();
-#endif
-    constexpr int NS = T::NS, MF = T::MF, NF = T::NF, WNT = T::WNT, NC = T::NC, ROWB = T::ROWB;
-    __shared__ __attribute__((aligned(16))) char lds[T::LDS_BYTES];
+constexpr int CUS_PER_XCD = 32;    // MI355X: 256 CUs in 8 XCDs
+constexpr int SPLITK_SLOTS = 8 * CUS_PER_XCD;  // workspace slots: at most one piece per CU in the split round
+constexpr int SPLITK_MIN_SLICES = 4;  // a piece covers at least this many K slices (below that its prologue and its
+                                      // partial-tile store cost more than the idle CU they fill)
 
-    // ---- tiles of this block.  One-tile-per-block launches have gridDim.x == n_virtual; persistent launches (256 blocks,
-    //      one per CU) walk the same virtual block ids with stride gridDim.x (a multiple of 8, so a block keeps its XCD).
-    //      virtual block -> (row tile, col tile): XCD-contiguous chunks, then super-rows of RS row tiles ----
-    struct TileC { int ct, row_begin, row_end, expert; };
-    const int CT = p.col_tiles;
-    const int n_virtual = p.max_row_tiles * CT;
-    auto map_tile = [&](int vb, TileC &c) -> bool {
-        const int q8 = n_virtual >> 3, r8 = n_virtual & 7, xcd = vb & 7;
+// Work list of one grouped-GEMM launch, derived per block from the device-side group sizes (scalar work).
+// Shared by grouped_gemm_kernel and splitk_fixup_kernel: both must cut the list the same way.
+template <int BM>
+struct TileSched {
+    int RT;      // real row tiles: sum over the groups of ceil(rows / BM)
+    int T;       // real tiles = RT * col_tiles
+    int smax;    // largest split factor allowed (1 = no split-K tail)
+
+    __device__ __forceinline__ TileSched(const GemmParams &p, int nk) {
+        int rt = 0;
+        for (int g = 0; g < p.G; ++g) rt += (p.group_offsets[g + 1] - p.group_offsets[g] + BM - 1) / BM;
+        RT = rt;
+        T = rt * p.col_tiles;
+        int m = p.splitk_max < nk / SPLITK_MIN_SLICES ? p.splitk_max : nk / SPLITK_MIN_SLICES;
+        smax = m < 1 ? 1 : m;
+    }
+    // the eighth of the list that XCD x takes: [start, start + n)
+    __device__ __forceinline__ void chunk(int x, int &start, int &n) const {
+        const int q8 = T >> 3, r8 = T & 7;
 #ifdef GEMM_NO_XCD
-        const int swz = vb; (void)q8; (void)r8; (void)xcd;
+        start = 0; n = T; (void)q8; (void)r8; (void)x;   // experiment: plain order (the caller then passes x = 0 semantics)
 #else
-        const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+        n = q8 + (x < r8 ? 1 : 0);
+        start = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
 #endif
-        const int RS = p.rs;
+    }
+    // split factor of XCD chunk of n tiles: full = tiles run whole, rm = tiles of the last partial round, each cut in s
+    __device__ __forceinline__ void tail(int n, int &full, int &rm, int &s) const {
+        full = (n / CUS_PER_XCD) * CUS_PER_XCD;
+        rm = n - full;
+        s = 1;
+        if (rm > 0 && smax >= 2) {
+            s = CUS_PER_XCD / rm;
+            if (s > smax) s = smax;
+        }
+        if (s < 2) { s = 1; full = n; rm = 0; }
+    }
+    // sequence index i of XCD x -> (tile index in the list, K piece split of nsplit, workspace slot or -1)
+    __device__ __forceinline__ bool decode(int x, int i, int &swz, int &split, int &nsplit, int &slot) const {
+        int start, n, full, rm, s;
+        chunk(x, start, n);
+        tail(n, full, rm, s);
+        if (i < full) { swz = start + i; split = 0; nsplit = 1; slot = -1; return true; }
+        const int j = i - full;
+        if (j >= rm * s) return false;
+        swz = start + full + j % rm;   // neighbouring tiles stay neighbours: the pieces of one K range run side by side
+        split = j / rm;
+        nsplit = s;
+        slot = x * CUS_PER_XCD + j;
+        return true;
+    }
+    // tile index in the list -> column tile, row range, expert
+    __device__ __forceinline__ void tile(const GemmParams &p, int swz, int &ct, int &row_begin, int &row_end, int &expert) const {
+        const int CT = p.col_tiles, RS = p.rs;
+        ct = 0; row_begin = 0; row_end = 0; expert = 0;
         if (RS <= 0) {
             // Group-major order (weight-streaming regime, a few row tiles per group): all row tiles of one (group, column
             // tile) are consecutive, the column tiles of a group follow each other.  The blocks an XCD runs together then
@@ -161,45 +197,74 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 const int nt = (e - b + BM - 1) / BM;
                 if (swz < base + nt * CT) {
                     const int local = swz - base;
-                    c.ct = local / nt;
-                    c.row_begin = b + (local - c.ct * nt) * BM;
-                    c.row_end = e;
-                    c.expert = g % p.n_experts;
-                    return true;
+                    ct = local / nt;
+                    row_begin = b + (local - ct * nt) * BM;
+                    row_end = e;
+                    expert = g % p.n_experts;
+                    return;
                 }
                 base += nt * CT;
             }
-            return false;
+            return;
         }
+        // super-rows of RS row tiles: an XCD's 32 CUs work on RS x (32 / RS) tiles at a time
         const int per_sr = RS * CT;
         const int sr = swz / per_sr;
         const int rem = swz - sr * per_sr;
-        const int rows_in = min(RS, p.max_row_tiles - sr * RS);
+        const int rows_in = min(RS, RT - sr * RS);
         const int ctile = rem / rows_in;
         const int rt = sr * RS + (rem - ctile * rows_in);
-        // row tile -> group (expert), row range
         int tile0 = 0;
         for (int g = 0; g < p.G; ++g) {
             const int b = p.group_offsets[g], e = p.group_offsets[g + 1];
             const int nt = (e - b + BM - 1) / BM;
             if (rt < tile0 + nt) {
-                c.ct = ctile;
-                c.row_begin = b + (rt - tile0) * BM;
-                c.row_end = e;
-                c.expert = g % p.n_experts;
-                return true;
+                ct = ctile;
+                row_begin = b + (rt - tile0) * BM;
+                row_end = e;
+                expert = g % p.n_experts;
+                return;
             }
             tile0 += nt;
         }
-        return false;  // surplus tile of the worst-case grid
+    }
+};
+
+template <int DT, int EPI, int BM, int BNW>
+__global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmParams p) {
+    using T = Tile<EPI, BM, BNW>;
+    typedef Elt<DT> E;                    // element type of the operands and of the output (bf16 / fp16)
+    typedef typename E::frag_t bf16x8_t;  // 8 K-consecutive elements: one MFMA operand
+#ifdef GEMM_STAMPS
+    const unsigned long long st_entry = stamp();
+#endif
+    constexpr int NS = T::NS, MF = T::MF, NF = T::NF, WNT = T::WNT, NC = T::NC, ROWB = T::ROWB;
+    __shared__ __attribute__((aligned(16))) char lds[T::LDS_BYTES];
+
+    // ---- tiles of this block.  The launch is a list of T real tiles (T from the device-side group sizes, so the worst-case
+    //      grid needs no host sync).  The 8 XCDs each take one contiguous eighth of the list (blocks b and b + 8 share an
+    //      XCD: its L2 then sees neighbouring tiles) and walk it in sequence order i = b >> 3, i + gridDim/8, ...
+    //      (one-tile-per-block launches: one step; persistent launches: 256 blocks, one per CU).
+    //      Split-K tail: an XCD's 32 CUs run its eighth in rounds of 32 tiles; the last, partial round of Rm < 32 tiles
+    //      leaves CUs idle.  With a workspace, each of those Rm tiles is cut along K into s = floor(32 / Rm) pieces that
+    //      fill the round; a piece leaves its fp32 accumulators in the workspace (slot = xcd * 32 + piece) and
+    //      splitk_fixup_kernel, launched right behind, adds a tile's pieces in K order and runs the epilogue: fixed order,
+    //      no atomics, bit-reproducible from call to call. ----
+    struct TileC { int ct, row_begin, row_end, expert, kb, ke, slot; };
+    const int nk = p.K / BK;  // >= 1 (K % 64 == 0)
+    const TileSched<BM> sch(p, nk);
+    auto locate = [&](int i, TileC &c) -> bool {  // sequence index of this block's XCD -> work item
+        int swz, split, nsplit;
+        if (!sch.decode((int)blockIdx.x & 7, i, swz, split, nsplit, c.slot)) return false;
+        sch.tile(p, swz, c.ct, c.row_begin, c.row_end, c.expert);
+        c.kb = (int)((long long)split * nk / nsplit);
+        c.ke = (int)((long long)(split + 1) * nk / nsplit);
+        return true;
     };
-    auto next_tile = [&](int vb, TileC &c) {  // first real tile of this block at or after virtual block vb
-        while (vb < n_virtual && !map_tile(vb, c)) vb += (int)gridDim.x;
-        return vb;
-    };
+    const int seq_stride = (int)gridDim.x >> 3;  // gridDim.x is a multiple of 8
     TileC cur, nxt;
-    int vb = next_tile((int)blockIdx.x, cur);
-    if (vb >= n_virtual) return;  // uniform per block
+    int vb = (int)blockIdx.x >> 3;
+    if (!locate(vb, cur)) return;  // uniform per block
     int ct = cur.ct, row_begin = cur.row_begin, row_end = cur.row_end, expert = cur.expert;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -252,18 +317,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             } else {
                 wrow = min(tc.ct * BNW + row, p.N_out - 1);
             }
-            w_src[j] = wb + (long long)wrow * p.K + cs * 8;
+            w_src[j] = wb + (long long)wrow * p.ldw + cs * 8;
         }
     };
     bf16_t *const lds_e = reinterpret_cast<bf16_t *>(lds);
-    const int nk = p.K / BK;  // >= 1 (K % 64 == 0)
+    int kbase = cur.kb;  // first K slice of the work item being staged
     auto stage = [&](int buf, int kt) {
         if (!loader) return;
         bf16_t *slot = lds_e + buf * T::SLOT_ELEMS;
 #pragma unroll
-        for (int j = 0; j < NPX; ++j) glds16(a_src[j] + kt * BK, slot + (lwave * NPX + j) * 512);
+        for (int j = 0; j < NPX; ++j) glds16(a_src[j] + (kbase + kt) * BK, slot + (lwave * NPX + j) * 512);
 #pragma unroll
-        for (int j = 0; j < NPW; ++j) glds16(w_src[j] + kt * BK, slot + BM * BK + (lwave * NPW + j) * 512);
+        for (int j = 0; j < NPW; ++j) glds16(w_src[j] + (kbase + kt) * BK, slot + BM * BK + (lwave * NPW + j) * 512);
     };
 
     // ---- fragment read offsets (elements): lane (fr, fq) reads row 16*t + fr, k chunk ks*4 + fq ----
@@ -284,7 +349,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     constexpr bool OVERLAP = T::OVERLAP;
     char *const img = lds + (OVERLAP ? T::SLOT_BYTES : 0);
 
-    auto tile_body = [&](auto mfw_c, auto loads_c, const int row_off, const bool staged, const bool have_next) {
+    // returns true when the work item was a K piece (accumulators left in the workspace, nothing to store)
+    auto tile_body = [&](auto mfw_c, auto loads_c, const int row_off, const bool staged, const bool have_next) -> bool {
         constexpr int MFW = decltype(mfw_c)::value;
         constexpr bool LOADS = decltype(loads_c)::value != 0;  // false: this wave never issues LDS-DMA (pointers dead)
         const int x_off = (row_off + fr) * BK;
@@ -300,15 +366,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         // instructions per loader wave each.
         // (a persistent launch staged this tile's slice 0 under the previous tile's epilogue; deeper rings fill their other
         // slots once every wave has read the previous tile's image out of them)
+        const int nkl = cur.ke - cur.kb;  // K slices of this work item (the whole K range, or one piece of it)
         if (OVERLAP && NS > 2 && staged) __syncthreads();
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s)
-            if (LOADS && !(staged && s == 0) && s < nk) stage(s, s);
+            if (LOADS && !(staged && s == 0) && s < nkl) stage(s, s);
 #ifdef GEMM_STAMPS
         st_t0 = stamp(); st_begin = st_t0;
 #endif
-        for (int kt = 0; kt < nk; ++kt) {
-            const int ahead = nk - 1 - kt;
+        for (int kt = 0; kt < nkl; ++kt) {
+            const int ahead = nkl - 1 - kt;
             static_assert((NS - 2) * PP < 64, "vmcnt field");
             switch (ahead < NS - 2 ? ahead : NS - 2) {
                 case 0: wait_vm_barrier<0>(); break;
@@ -323,7 +390,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             const unsigned long long st_t1 = stamp();
 #endif
 #ifndef GEMM_ABLATE_NO_LOAD
-            if (LOADS && kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
+            if (LOADS && kt + NS - 1 < nkl) stage((kt + NS - 1) % NS, kt + NS - 1);
 #endif
 #ifdef GEMM_STAMPS
             const unsigned long long st_t2 = stamp();
@@ -411,12 +478,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         st_loop_end = stamp();
 #endif
 
+        if (cur.slot >= 0) {
+            // K piece of a split tile: the fp32 accumulators go to the workspace as they are, one 1-KiB block per 16 x 16
+            // fragment in (lane, register) order -- fully coalesced; splitk_fixup_kernel reads them the same way
+            // (buffer stores: one VGPR of address -- lane * 16 -- and a scalar offset per fragment; with per-lane 64-bit
+            // pointers the addresses of all fragments were computed up front and the 256 x 256 kernels spilled)
+            float *ws = p.splitk_ws + (size_t)cur.slot * (size_t)(BM * BNW);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, BM * BNW * 4, 0x00020000);
+            const int sbase = __builtin_amdgcn_readfirstlane(((row_off / 16) * (BNW / 16) + wn * NF) * 1024);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < MFW; ++mf)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v_t, acc[nf][mf]), rsrc, lane * 16,
+                                                           sbase + (mf * (BNW / 16) + nf) * 1024, 0);
+            __syncthreads();  // every wave is done reading the ring
+            return true;
+        }
         // ---- epilogue: activation in registers -> bf16 tile image in LDS -> 16-byte, full-line global stores ----
         const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
         __syncthreads();  // every wave is done reading the ring
         if (OVERLAP && LOADS && have_next) {
             // persistent launch: the loader waves start the next tile (pointers, first slice into ring slot 0) while the
             // epilogue runs; the output image sits behind slot 0 for that
+            kbase = nxt.kb;
             setup_ptrs(nxt);
             stage(0, 0);
         }
@@ -507,6 +592,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 }
             }
         }
+        return false;
     };
     // ASYM (256 x 256 tile): the loader waves (0-3, rows 0..79) own 5 row fragments, their SIMD partners (4-7, rows
     // 80..255) own 11.  A loader wave is blocked ~1000-1400 cycles per slice issuing the LDS-DMA before it can start its
@@ -527,12 +613,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         constexpr bool LOADS_W = decltype(loads_c)::value != 0;
         bool staged = false;
         while (true) {
+            if (!staged) kbase = cur.kb;
             if (LOADS_W && loader && !staged) setup_ptrs(cur);
-            const int vbn = next_tile(vb + (int)gridDim.x, nxt);
-            const bool have_next = vbn < n_virtual;
-            tile_body(mfw_c, loads_c, row_off, staged, have_next);
-            __syncthreads();
-            {
+            const int vbn = vb + seq_stride;
+            const bool have_next = locate(vbn, nxt);
+            const bool piece = tile_body(mfw_c, loads_c, row_off, staged, have_next);
+            if (!piece) {
+                __syncthreads();
                 constexpr int CPR = NC / 8;                    // 16-byte chunks per row
                 constexpr int ROWS_PER_IT = NTHREADS / CPR;    // rows covered by one pass of the block
                 const int cc = tid % CPR, r0 = tid / CPR;
@@ -608,8 +695,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
                 }
             }
             if (!have_next) break;
-            if (!OVERLAP) __syncthreads();  // the image has been read before the next tile's first slice lands on it
-            staged = OVERLAP;
+            if (!OVERLAP && !piece) __syncthreads();  // the image has been read before the next tile's first slice lands on it
+            staged = OVERLAP && !piece;
             vb = vbn;
             cur = nxt;
             ct = cur.ct; row_begin = cur.row_begin; row_end = cur.row_end; expert = cur.expert;
@@ -634,6 +721,93 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 #endif
 }
 
+// Fix-up of the split-K tail: adds the K pieces of every split tile in K order (fixed order: bit-reproducible) and runs
+// the epilogue of grouped_gemm_kernel on the sums -- same bias / rounding / activation sequence, so a split tile differs
+// from a whole one only through the fp32 summation order over K.  One block = one (XCD x, tile t of its last round, part)
+// triple; a wave takes (row fragment, output column fragment) pairs, reads the pieces' 1-KiB fragment blocks (coalesced,
+// in the (lane, register) order the pieces were stored in) and stores 4 consecutive outputs per lane.
+// HBM-bound: s * BM * BNW * 4 bytes read per split tile (at most 128 split tiles per launch).
+constexpr int FIXUP_PARTS = 8;
+template <int DT, int EPI, int BM, int BNW>
+__global__ __launch_bounds__(256) void splitk_fixup_kernel(const GemmParams p) {
+    using T = Tile<EPI, BM, BNW>;
+    typedef Elt<DT> E;
+    constexpr int NC = T::NC, NF = T::NF, WNT = T::WNT;
+    constexpr int TF = BM / 16;    // row fragments of a tile
+    constexpr int OCF = NC / 16;   // output column fragments of a tile
+    constexpr int WCF = BNW / 16;  // W-row fragments (columns of the accumulator tile)
+    const int part = (int)blockIdx.x % FIXUP_PARTS;
+    const int tl = ((int)blockIdx.x / FIXUP_PARTS) % (CUS_PER_XCD / 2);
+    const int x = (int)blockIdx.x / (FIXUP_PARTS * (CUS_PER_XCD / 2));
+    const TileSched<BM> sch(p, p.K / BK);
+    int start, n, full, rm, s;
+    sch.chunk(x, start, n);
+    sch.tail(n, full, rm, s);
+    if (s < 2 || tl >= rm) return;  // uniform per block: this XCD's last round was not split, or has fewer tiles
+    int ct, row_begin, row_end, expert;
+    sch.tile(p, start + full + tl, ct, row_begin, row_end, expert);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    // piece q of this tile sits in slot x * 32 + q * rm + tl (TileSched::decode)
+    const float *ws0 = p.splitk_ws + (size_t)(x * CUS_PER_XCD + tl) * (size_t)(BM * BNW);
+    const size_t piece_stride = (size_t)rm * (size_t)(BM * BNW);
+    const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
+    auto frag_sum = [&](int rf, int wf) {
+        const float *src = ws0 + ((size_t)(rf * WCF + wf) * 64 + lane) * 4;
+        f32x4_t v = *reinterpret_cast<const f32x4_t *>(src);
+        for (int q = 1; q < s; ++q) v += *reinterpret_cast<const f32x4_t *>(src + q * piece_stride);
+        return v;
+    };
+    for (int item = part * 4 + wave; item < TF * OCF; item += FIXUP_PARTS * 4) {
+        const int rf = item / OCF, cf = item % OCF;
+        const int prow = row_begin + rf * 16 + fr;
+        uint2 o;
+        int c0;
+        if (EPI == EPI_SWIGLU) {
+            // output column fragment cf of the tile = 'a' fragment nfa of wave column group wq and its 'b' partner
+            constexpr int OF = NF / 2 > 0 ? NF / 2 : 1;
+            const int wq = cf / OF, nfa = cf % OF;
+            const f32x4_t av = frag_sum(rf, wq * NF + nfa), bv = frag_sum(rf, wq * NF + nfa + NF / 2);
+            c0 = ct * NC + wq * (WNT / 2) + nfa * 16 + fq * 4;
+            float a[4], b[4], sg[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = av[j];
+                b[j] = bv[j];
+            }
+            if (bias && c0 < p.N_out) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] += E::to_f(bias[c0 + j]);
+                    b[j] += E::to_f(bias[p.b_row_offset + c0 + j]);
+                }
+            }
+            round2<DT>(a[0], a[1]); round2<DT>(a[2], a[3]); round2<DT>(b[0], b[1]); round2<DT>(b[2], b[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sg[j] = fast_silu(a[j]);
+            round2<DT>(sg[0], sg[1]); round2<DT>(sg[2], sg[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sg[j] = (c0 + j < p.n_gated) ? sg[j] : 1.0f;   // RePaMLP mask
+            o.x = E::pack2(sg[0] * b[0], sg[1] * b[1]);
+            o.y = E::pack2(sg[2] * b[2], sg[3] * b[3]);
+        } else {
+            const f32x4_t av = frag_sum(rf, cf);
+            c0 = ct * NC + cf * 16 + fq * 4;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = av[j] + ((bias && c0 < p.N_out) ? E::to_f(bias[c0 + j]) : 0.f);
+            if (EPI == EPI_GELU_NEW) {
+                round2<DT>(v[0], v[1]); round2<DT>(v[2], v[3]);
+                gelu_new_pair<DT>(v[0], v[1]);
+                gelu_new_pair<DT>(v[2], v[3]);
+            }
+            o.x = E::pack2(v[0], v[1]);
+            o.y = E::pack2(v[2], v[3]);
+        }
+        if (prow < row_end && c0 < p.N_out) *reinterpret_cast<uint2 *>(p.out + (long long)prow * p.ldo + c0) = o;
+    }
+}
+
 // Tile choice.  rows_hint = host upper bound of the mean rows per group.  The 256-row tile is the MFMA-bound one; below
 // that the job is weight streaming: smaller row tiles waste fewer X rows and leave LDS for more weight slices in
 // flight, and the narrow column tile gives fc2-shaped launches (N = hidden size) enough blocks to cover the chip.
@@ -655,12 +829,11 @@ static TileChoice choose_tile(int epilogue, int max_rows, int G, int N) {
         const long long row_tiles = (max_rows + t.bm - 1) / t.bm;
         if (row_tiles * ((N + 255) / 256) < 128) t.bnw = row_tiles * ((N + 127) / 128) >= 128 ? 128 : 64;
     }
-    if (const char *env = getenv("MOE_GEMM_TILE")) {
-        int bm = 0, bnw = 0;
-        if (sscanf(env, "%d,%d", &bm, &bnw) == 2) {
-            if (bm == 256 || bm == 128 || bm == 64 || bm == 32) t.bm = bm;
-            if (bnw == 256 || bnw == 128 || (bnw == 64 && epilogue != MOE_EPI_SWIGLU)) t.bnw = bnw;
-        }
+    const Knobs &kn = knobs();
+    if (kn.tile_bm || kn.tile_bnw) {
+        const int bm = kn.tile_bm, bnw = kn.tile_bnw;
+        if (bm == 256 || bm == 128 || bm == 64 || bm == 32) t.bm = bm;
+        if (bnw == 256 || bnw == 128 || (bnw == 64 && epilogue != MOE_EPI_SWIGLU)) t.bnw = bnw;
     }
     return t;
 }
@@ -668,20 +841,27 @@ static TileChoice choose_tile(int epilogue, int max_rows, int G, int N) {
 template <int DT, int EPI, int BM, int BNW>
 static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     constexpr int NC = Tile<EPI, BM, BNW>::NC;
+    const Knobs &kn = knobs();
     p.max_row_tiles = max_rows_or_neg / BM + p.G;  // sum_g ceil(rows_g / BM) <= floor(sum rows / BM) + G
     p.col_tiles = (p.N_out + NC - 1) / NC;
     // super-row height: 4 row tiles (an XCD's 32 CUs then work on 4 x 8 tiles); launches with few column tiles (fc2 of
     // config 2: 8) measured 2 % faster with 3 (same-process A/B: 811 -> 793 us; fc1 with 44 column tiles 0.7 % slower)
     p.rs = GEMM_RS > 0 ? GEMM_RS : (p.col_tiles <= 8 ? 3 : 4);
-    // small row tiles = few rows per group = weight streaming: group-major tile order (see map_tile); MOE_GEMM_ORDER=0/1 forces
-    // super-rows / group-major for A/B runs
+    // small row tiles = few rows per group = weight streaming: group-major tile order (see TileSched::tile);
+    // MOE_GEMM_ORDER=0/1 forces super-rows / group-major for A/B runs
     if (BM < 256) p.rs = 0;
-    if (const char *env = getenv("MOE_GEMM_ORDER")) {
-        if (env[0] == '0' && p.rs == 0) p.rs = 4;
-        if (env[0] == '1') p.rs = 0;
-    }
-    long long grid = (long long)p.max_row_tiles * p.col_tiles;
-    if (grid <= 0) return 0;
+    if (kn.order == 0 && p.rs == 0) p.rs = 4;
+    if (kn.order == 1) p.rs = 0;
+    const long long tiles = (long long)p.max_row_tiles * p.col_tiles;  // worst case; the kernel counts the real ones
+    if (tiles <= 0) return 0;
+    // Split-K tail (see the kernel): needs the caller's workspace, one BM x BNW fp32 slot per CU; the backward epilogues
+    // that read pre-activations in their store phase are never split.
+    constexpr bool CAN_SPLIT = EPI == EPI_PLAIN || EPI == EPI_SWIGLU || EPI == EPI_GELU_NEW;
+    const bool split = CAN_SPLIT && p.splitk_ws != nullptr && p.splitk_max >= 2 && p.K / BK >= 2 * SPLITK_MIN_SLICES;
+    if (!split) { p.splitk_ws = nullptr; p.splitk_max = 1; }
+    // one block per work item: every XCD's sequence is at most ceil(tiles / 8) whole tiles (+ up to 32 pieces in place of
+    // its last partial round); the grid is a multiple of 8 so that block b's XCD is b & 7 whatever the size
+    long long grid = 8 * ((tiles + 7) / 8 + (split ? CUS_PER_XCD : 0));
     if (grid > 0x7fffffffLL) return fail(MOE_ERR_SHAPE, "grouped_gemm: grid too large");
     // big-tile launches: one persistent block per CU walks the tile list (no block hand-over between tiles, and for
     // SwiGLU the next tile's first fills overlap the epilogue); MOE_NO_PERSIST=1 keeps one block per tile
@@ -689,10 +869,18 @@ static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     // blocks, could no longer interleave with a second stream's launch, so they keep one block per tile)
     // Small row tiles, -DGEMM_OVERLAP_SMALL=1 builds only: launches of more than one round run persistent too, with the
     // next tile's pointers and first slice under the epilogue.
-    if (GEMM_PERSIST && BM == 256 && BNW == 256 && grid >= 4096 && !getenv("MOE_NO_PERSIST")) grid = 256;
-    if (BM < 256 && Tile<EPI, BM, BNW>::OVERLAP && grid > 256 && !getenv("MOE_NO_PERSIST")) grid = 256;
+    if (GEMM_PERSIST && BM == 256 && BNW == 256 && tiles >= 4096 && !kn.no_persist) grid = 8 * CUS_PER_XCD;
+    if (BM < 256 && Tile<EPI, BM, BNW>::OVERLAP && tiles > 256 && !kn.no_persist) grid = 8 * CUS_PER_XCD;
     hipLaunchKernelGGL((grouped_gemm_kernel<DT, EPI, BM, BNW>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, p);
-    return check_launch("grouped_gemm_kernel");
+    int rc = check_launch("grouped_gemm_kernel");
+    if (rc || !split) return rc;
+    if constexpr (CAN_SPLIT) {
+        // fix-up of the split tiles: one block per (XCD, tile of its last round, part of the tile); blocks whose tile was
+        // not split (the decision is the device's) exit at once
+        hipLaunchKernelGGL((splitk_fixup_kernel<DT, EPI, BM, BNW>), dim3(8 * CUS_PER_XCD / 2 * FIXUP_PARTS), dim3(256), 0, st, p);
+        rc = check_launch("splitk_fixup_kernel");
+    }
+    return rc;
 }
 
 template <int DT, int EPI>
@@ -748,7 +936,7 @@ extern "C" int moe_debug_read_stamps(unsigned long long *host_dst) {
 static int grouped_gemm_launch(const char *fn, int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                const void *w, const void *bias, const int32_t *group_offsets, int G, int n_experts_local,
                                int max_rows, int K, int N, int n_gated, void *out, int64_t ldo, const void *aux,
-                               int64_t ld_aux, int dtype, void *stream) {
+                               int64_t ld_aux, void *splitk_ws, size_t splitk_ws_bytes, int dtype, void *stream) {
     if (dtype != MOE_DTYPE_BF16 && dtype != MOE_DTYPE_F16) return fail(MOE_ERR_ARG, "%s: unknown dtype %d", fn, dtype);
     int rc = gemm_args_ok(fn, a, lda, gather_shift, w, group_offsets, G, n_experts_local, max_rows, K, N, out, ldo);
     if (rc) return rc;
@@ -773,12 +961,25 @@ static int grouped_gemm_launch(const char *fn, int epilogue, const void *a, int6
     p.ld_aux = ld_aux;
     p.dtype = dtype;
     hipStream_t st = (hipStream_t)stream;
-    p.w_expert_stride = (epilogue == MOE_EPI_SWIGLU ? 2ll : 1ll) * N * K;
+#ifdef GEMM_EXP_LDW_PAD
+    p.ldw = K + GEMM_EXP_LDW_PAD;  // experiment (tools/gemm_bench.py --pad): weight rows padded like the activations
+#else
+    p.ldw = K;
+#endif
+    p.w_expert_stride = (epilogue == MOE_EPI_SWIGLU ? 2ll : 1ll) * N * p.ldw;
     p.bias_expert_stride = (epilogue == MOE_EPI_SWIGLU ? 2ll : 1ll) * N;
     // decode steps (at most 64 compact rows in the whole launch): weight-streaming GEMV-style kernel, no LDS tiles
-    if (max_rows <= SKINNY_MAX_ROWS && epilogue <= MOE_EPI_GELU_NEW && !getenv("MOE_NO_SKINNY"))
+    if (max_rows <= SKINNY_MAX_ROWS && epilogue <= MOE_EPI_GELU_NEW && !knobs().no_skinny)
         return launch_skinny_gemm(p, epilogue, max_rows, st);
     const TileChoice t = choose_tile(epilogue, max_rows, G, N);
+    // split-K tail: one fp32 tile slot per CU in the caller's workspace (moe_splitk_workspace_bytes() covers every tile)
+    p.splitk_ws = nullptr;
+    p.splitk_max = 1;
+    if (splitk_ws && aligned16(splitk_ws) && knobs().splitk >= 2 &&
+        splitk_ws_bytes >= (size_t)SPLITK_SLOTS * t.bm * t.bnw * sizeof(float)) {
+        p.splitk_ws = (float *)splitk_ws;
+        p.splitk_max = knobs().splitk;
+    }
     if (dtype == MOE_DTYPE_F16) {  // forward epilogues only: the backward entry points are bf16
         switch (epilogue) {
             case MOE_EPI_SWIGLU: return launch_gemm<DT_F16, EPI_SWIGLU>(p, max_rows, t, st);
@@ -796,20 +997,24 @@ static int grouped_gemm_launch(const char *fn, int epilogue, const void *a, int6
     }
 }
 
+extern "C" size_t moe_splitk_workspace_bytes(void) { return (size_t)SPLITK_SLOTS * 256 * 256 * sizeof(float); }
+
 extern "C" int moe_grouped_gemm_fwd(int epilogue, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                     const void *w, const void *bias, const int32_t *group_offsets, int G,
                                     int n_experts_local, int max_rows, int K, int N, int n_gated, void *out, int64_t ldo,
-                                    int dtype, void *stream) {
+                                    void *splitk_ws, size_t splitk_ws_bytes, int dtype, void *stream) {
     if (epilogue != MOE_EPI_PLAIN && epilogue != MOE_EPI_SWIGLU && epilogue != MOE_EPI_GELU_NEW)
         return fail(MOE_ERR_ARG, "moe_grouped_gemm_fwd: unknown epilogue %d", epilogue);
     return grouped_gemm_launch("moe_grouped_gemm_fwd", epilogue, a, lda, gather, gather_shift, w, bias, group_offsets, G,
-                               n_experts_local, max_rows, K, N, n_gated, out, ldo, nullptr, 0, dtype, stream);
+                               n_experts_local, max_rows, K, N, n_gated, out, ldo, nullptr, 0, splitk_ws, splitk_ws_bytes,
+                               dtype, stream);
 }
 
 extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                   const void *w1, const void *b1, const void *w2, const void *b2,
                                   const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
-                                  int n_gated, void *h_ws, void *y, int dtype, void *stream) {
+                                  int n_gated, void *h_ws, void *y, void *splitk_ws, size_t splitk_ws_bytes, int dtype,
+                                  void *stream) {
     if (!h_ws || !y || !w2) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: null pointer");
     if (dtype != MOE_DTYPE_BF16 && dtype != MOE_DTYPE_F16) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: unknown dtype %d", dtype);
     if (act != MOE_ACT_SWIGLU && act != MOE_ACT_GELU_NEW) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd: unknown act %d", act);
@@ -819,16 +1024,18 @@ extern "C" int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int
     int rc = gemm_args_ok("moe_expert_ffn_fwd", h_ws, I, 0, w2, group_offsets, G, n_experts_local, max_rows, I, M, y, M);
     if (rc) return rc;
     rc = moe_grouped_gemm_fwd(act == MOE_ACT_SWIGLU ? MOE_EPI_SWIGLU : MOE_EPI_GELU_NEW, a, lda, gather, gather_shift, w1, b1,
-                              group_offsets, G, n_experts_local, max_rows, M, I, n_gated, h_ws, I, dtype, stream);
+                              group_offsets, G, n_experts_local, max_rows, M, I, n_gated, h_ws, I, splitk_ws, splitk_ws_bytes,
+                              dtype, stream);
     if (rc) return rc;
     return moe_grouped_gemm_fwd(MOE_EPI_PLAIN, h_ws, I, nullptr, 0, w2, b2, group_offsets, G, n_experts_local, max_rows, I, M,
-                                -1, y, M, dtype, stream);
+                                -1, y, M, splitk_ws, splitk_ws_bytes, dtype, stream);
 }
 
 extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, const int32_t *gather, int gather_shift,
                                         const void *w1, const void *b1, const void *w2, const void *b2,
                                         const int32_t *group_offsets, int G, int n_experts_local, int max_rows, int M, int I,
-                                        int n_gated, void *ab, void *h, void *y, void *stream) {
+                                        int n_gated, void *ab, void *h, void *y, void *splitk_ws, size_t splitk_ws_bytes,
+                                        void *stream) {
     if (!ab || !h || !y || !w2) return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd_train: null pointer");
     if (act != MOE_ACT_SWIGLU && act != MOE_ACT_GELU_NEW)
         return fail(MOE_ERR_ARG, "moe_expert_ffn_fwd_train: unknown act %d", act);
@@ -840,18 +1047,19 @@ extern "C" int moe_expert_ffn_fwd_train(int act, const void *a, int64_t lda, con
     const int N1 = act == MOE_ACT_SWIGLU ? 2 * I : I;
     // fc1 with the plain epilogue: the packed [a | b] rows of W1 give AB = [a | b] columns (bf16, bias added)
     rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, a, lda, gather, gather_shift, w1, b1, group_offsets, G, n_experts_local, max_rows,
-                              M, N1, -1, ab, N1, MOE_DTYPE_BF16, stream);
+                              M, N1, -1, ab, N1, splitk_ws, splitk_ws_bytes, MOE_DTYPE_BF16, stream);
     if (rc) return rc;
     if (max_rows == 0) return 0;
     rc = launch_act_fwd(act, (const bf16_t *)ab, group_offsets, G, max_rows, I, n_gated, (bf16_t *)h, (hipStream_t)stream);
     if (rc) return rc;
     return moe_grouped_gemm_fwd(MOE_EPI_PLAIN, h, I, nullptr, 0, w2, b2, group_offsets, G, n_experts_local, max_rows, I, M,
-                                -1, y, M, MOE_DTYPE_BF16, stream);
+                                -1, y, M, splitk_ws, splitk_ws_bytes, MOE_DTYPE_BF16, stream);
 }
 
 namespace {
 struct BwdWs {
     bf16_t *wt, *dab, *xr;
+    float *splitk;
     size_t total;
 };
 inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -868,6 +1076,7 @@ BwdWs carve_bwd(void *ws, int act, int G, int El, int max_rows, int M, int I) {
     r.wt = (bf16_t *)take(2 * (size_t)El * M * N1);        // W2^T, then W1^T
     r.dab = (bf16_t *)take(2 * (size_t)max_rows * N1);
     r.xr = (bf16_t *)take(2 * (size_t)max_rows * M);       // gathered input rows (only when a gather index is given)
+    r.splitk = (float *)take(moe_splitk_workspace_bytes()); // K pieces of the split-K tail of the data-gradient launches
     r.total = off;
     (void)G;
     return r;
@@ -916,14 +1125,15 @@ extern "C" int moe_expert_ffn_bwd(int act, const void *a, int64_t lda, const int
     // dH = dY @ W2 never reaches HBM: the store phase of this launch turns each dH chunk into dAB with the kept
     // pre-activations (same arithmetic and rounding as act_bwd_kernel on a bf16 dH)
     if ((rc = grouped_gemm_launch(fn, act == MOE_ACT_SWIGLU ? EPI_DSWIGLU : EPI_DGELU, dy, M, nullptr, 0, ws.wt, nullptr,
-                                  group_offsets, G, El, max_rows, M, I, n_gated, ws.dab, N1, ab, N1, MOE_DTYPE_BF16, stream)))
+                                  group_offsets, G, El, max_rows, M, I, n_gated, ws.dab, N1, ab, N1, nullptr, 0, MOE_DTYPE_BF16,
+                                  stream)))
         return rc;
     if ((rc = launch_wgrad_tn(dyp, M, (const bf16_t *)h, I, group_offsets, G, El, max_rows, M, I, (bf16_t *)dw2, st))) return rc;
     if (db2 && (rc = launch_bias_grad(dyp, group_offsets, G, El, max_rows, M, db2, st))) return rc;
     // ---- fc1: dA = dAB @ W1, dW1 = dAB^T @ A, db1 = colsum(dAB) ----
     if ((rc = launch_transpose_batched((const bf16_t *)w1, El, N1, M, ws.wt, st))) return rc;  // W1^T [El, M, N1]
     if ((rc = moe_grouped_gemm_fwd(MOE_EPI_PLAIN, ws.dab, N1, nullptr, 0, ws.wt, nullptr, group_offsets, G, El, max_rows, N1,
-                                   M, -1, da_rows, M, MOE_DTYPE_BF16, stream)))
+                                   M, -1, da_rows, M, ws.splitk, moe_splitk_workspace_bytes(), MOE_DTYPE_BF16, stream)))
         return rc;
     const bf16_t *xrows = (const bf16_t *)a;
     long long ldx = lda;

@@ -191,10 +191,8 @@ int launch_skinny_gemm(const GemmParams &p0, int epilogue, int max_rows, hipStre
     if (!gated) {
         const long long active = p.G < max_rows ? p.G : max_rows;  // groups that can hold rows
         nw = active * ((p.N_out + 31) / 32) >= 256 ? 2 : 1;
-        if (const char *env = getenv("MOE_SKINNY_NW")) {  // tuning knob
-            const int v = atoi(env);
-            if (v == 1 || v == 2) nw = v;
-        }
+        const int v = knobs().skinny_nw;  // tuning knob MOE_SKINNY_NW
+        if (v == 1 || v == 2) nw = v;
     }
     const int cols = 16 * nw;
     p.col_tiles = (p.N_out + cols - 1) / cols;
@@ -205,8 +203,8 @@ int launch_skinny_gemm(const GemmParams &p0, int epilogue, int max_rows, hipStre
     // the HBM latency) but not more than one round of resident waves (a second, partial round would double the time)
     int ks = 8;
     while (ks > 1 && grid * ks > (gated ? 2048 : 4096)) ks >>= 1;
-    if (const char *env = getenv("MOE_SKINNY_KS")) {  // tuning knob: force the K split (1, 2, 4, 8)
-        const int v = atoi(env);
+    {
+        const int v = knobs().skinny_ks;  // tuning knob MOE_SKINNY_KS: force the K split (1, 2, 4, 8)
         if (v == 1 || v == 2 || v == 4 || v == 8) ks = v;
     }
     const dim3 g((unsigned)grid), b(64 * ks);

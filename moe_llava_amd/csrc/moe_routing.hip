@@ -613,6 +613,44 @@ static RoutingWs carve(void *ws, int S, int E) {
 
 using namespace moe;
 
+namespace moe {
+namespace {
+Knobs g_knobs;
+bool g_knobs_read = false;
+std::mutex g_knobs_mu;
+void read_knobs(Knobs &k) {
+    k = Knobs{};
+    k.order = -1;
+    k.splitk = 8;
+    if (const char *env = getenv("MOE_GEMM_TILE")) {
+        int bm = 0, bnw = 0;
+        if (sscanf(env, "%d,%d", &bm, &bnw) == 2) { k.tile_bm = bm; k.tile_bnw = bnw; }
+    }
+    if (const char *env = getenv("MOE_GEMM_ORDER")) k.order = env[0] == '0' ? 0 : env[0] == '1' ? 1 : -1;
+    k.no_persist = getenv("MOE_NO_PERSIST") != nullptr;
+    k.no_skinny = getenv("MOE_NO_SKINNY") != nullptr;
+    k.no_gate_route_fusion = getenv("MOE_NO_GATE_ROUTE_FUSION") != nullptr;
+    if (const char *env = getenv("MOE_SKINNY_NW")) k.skinny_nw = atoi(env);
+    if (const char *env = getenv("MOE_SKINNY_KS")) k.skinny_ks = atoi(env);
+    if (const char *env = getenv("MOE_SPLITK")) k.splitk = atoi(env);
+}
+}  // namespace
+const Knobs &knobs() {
+    std::lock_guard<std::mutex> lock(g_knobs_mu);
+    if (!g_knobs_read) {
+        read_knobs(g_knobs);
+        g_knobs_read = true;
+    }
+    return g_knobs;
+}
+}  // namespace moe
+
+extern "C" void moe_reload_knobs(void) {
+    std::lock_guard<std::mutex> lock(moe::g_knobs_mu);
+    moe::read_knobs(moe::g_knobs);
+    moe::g_knobs_read = true;
+}
+
 extern "C" int moe_abi_version(void) { return MOE_ABI_VERSION; }
 extern "C" const char *moe_last_error(void) { return err_buf(); }
 

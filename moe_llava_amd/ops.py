@@ -120,6 +120,37 @@ def _on(dev: torch.device):
     return torch.cuda.device(dev)
 
 
+_SPLITK_WS = {}      # (device index, stream pointer) -> 64 MiB workspace of the split-K tail
+_SPLITK_BYTES = None
+
+
+def _splitk_ws(t: Tensor, st: int):
+    """(pointer, bytes) of the split-K workspace of the grouped GEMM launches on stream ``st`` of ``t``'s device
+    (include/moe_gfx950.h: moe_splitk_workspace_bytes).  One buffer per (device, stream), allocated on first use and kept:
+    launches on one stream are ordered, launches on different streams (the chunks of the expert-parallel exchange
+    alternate between two) must not share it.  ``MOE_SPLITK=0`` in the environment: no workspace, tiles stay whole."""
+    global _SPLITK_BYTES
+    if _SPLITK_BYTES is None:
+        import os
+        env = os.environ.get("MOE_SPLITK")
+        _SPLITK_BYTES = 0 if (env is not None and int(env) < 2) else int(_lib.load().moe_splitk_workspace_bytes())
+    if _SPLITK_BYTES == 0 or not t.is_cuda:
+        return None, 0
+    key = (t.device.index, st)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = torch.empty((_SPLITK_BYTES,), dtype=torch.uint8, device=t.device)
+        _SPLITK_WS[key] = ws
+    return ws.data_ptr(), _SPLITK_BYTES
+
+
+def reload_knobs() -> None:
+    """Have the library (and this module) read the MOE_* environment knobs again (tests, tuning tools)."""
+    global _SPLITK_BYTES
+    _SPLITK_BYTES = None
+    _lib.load().moe_reload_knobs()
+
+
 def _need(t: Tensor, name: str, dtype, ndim: Optional[int] = None) -> None:
     if not isinstance(t, Tensor):
         raise TypeError(f"{name}: expected a tensor")
@@ -350,22 +381,23 @@ def _expert_ffn_launch(act, a, gather_ptr, gather_shift, w1, b1, w2, b2, offs_pt
     b1p = b1.data_ptr() if b1 is not None else None
     b2p = b2.data_ptr() if b2 is not None else None
     st = _stream_ptr(a)
+    skp, skb = _splitk_ws(a, st)
     with _on(dev):
         if timer is None:
             rc = lib.moe_expert_ffn_fwd(act, a.data_ptr(), a.stride(0), gather_ptr, gather_shift, w1.data_ptr(), b1p,
                                         w2.data_ptr(), b2p, offs_ptr, G, n_local, max_rows, M, I, n_gated, h.data_ptr(),
-                                        y.data_ptr(), dt, st)
+                                        y.data_ptr(), skp, skb, dt, st)
             _lib.check(rc, "moe_expert_ffn_fwd")
         else:
             # same two launches through the single-GEMM primitive, with events between them
             epi = EPI_SWIGLU if act == ACT_SWIGLU else EPI_GELU_NEW
             timer.mark("fc1_begin")
             rc = lib.moe_grouped_gemm_fwd(epi, a.data_ptr(), a.stride(0), gather_ptr, gather_shift, w1.data_ptr(), b1p,
-                                          offs_ptr, G, n_local, max_rows, M, I, n_gated, h.data_ptr(), I, dt, st)
+                                          offs_ptr, G, n_local, max_rows, M, I, n_gated, h.data_ptr(), I, skp, skb, dt, st)
             _lib.check(rc, "moe_grouped_gemm_fwd(fc1)")
             timer.mark("fc1_end")
             rc = lib.moe_grouped_gemm_fwd(EPI_PLAIN, h.data_ptr(), I, None, 0, w2.data_ptr(), b2p, offs_ptr, G, n_local,
-                                          max_rows, I, M, -1, y.data_ptr(), M, dt, st)
+                                          max_rows, I, M, -1, y.data_ptr(), M, skp, skb, dt, st)
             _lib.check(rc, "moe_grouped_gemm_fwd(fc2)")
             timer.mark("fc2_end")
     return y
@@ -435,6 +467,8 @@ def block_top2(x: Tensor, wg_weight: Tensor, capacity: int, noise: Optional[Tens
     hy = torch.empty((rows * (I + M),), dtype=x.dtype, device=dev)   # h workspace, then y
     out = torch.empty((S, M), dtype=x.dtype, device=dev)
     hp = hy.data_ptr()
+    st = _stream_ptr(x)
+    skp, skb = _splitk_ws(x, st) if max_rows > 64 else (None, 0)     # decode-size launches take the GEMV-style kernel
     if noise_seed_dev is not None:
         _need(noise_seed_dev, "noise_seed_dev", torch.int64)
         if noise is not None or noise_seed_dev.numel() != 1 or noise_seed_dev.device != dev:
@@ -446,7 +480,7 @@ def block_top2(x: Tensor, wg_weight: Tensor, capacity: int, noise: Optional[Tens
                 int(capacity), int(bool(drop_tokens)), n_gated, r.ptr("expert_idx"), r.ptr("slot"), r.ptr("weight"),
                 r.ptr("exp_counts"), r.ptr("kept_counts"), r.ptr("expert_offsets"), r.ptr("perm"), r.ptr("l_aux"),
                 r.ptr("workspace"), ws_bytes, w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
-                b2.data_ptr() if b2 is not None else None, hp, hp + rows * I * 2, out.data_ptr(), dt, _stream_ptr(x))
+                b2.data_ptr() if b2 is not None else None, hp, hp + rows * I * 2, out.data_ptr(), skp, skb, dt, st)
         _lib.check(rc, "moe_block_top2_fwd_dseed")
         r._keep = hy
         return out, logits, r
@@ -457,7 +491,7 @@ def block_top2(x: Tensor, wg_weight: Tensor, capacity: int, noise: Optional[Tens
             int(capacity), int(bool(drop_tokens)), n_gated, r.ptr("expert_idx"), r.ptr("slot"), r.ptr("weight"),
             r.ptr("exp_counts"), r.ptr("kept_counts"), r.ptr("expert_offsets"), r.ptr("perm"), r.ptr("l_aux"),
             r.ptr("workspace"), ws_bytes, w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
-            b2.data_ptr() if b2 is not None else None, hp, hp + rows * I * 2, out.data_ptr(), dt, _stream_ptr(x))
+            b2.data_ptr() if b2 is not None else None, hp, hp + rows * I * 2, out.data_ptr(), skp, skb, dt, st)
     _lib.check(rc, "moe_block_top2_fwd")
     r._keep = hy                                   # y lives in hy; keep it alive with the routing (inspection only)
     return out, logits, r
@@ -564,12 +598,14 @@ def expert_ffn_train(act: int, a: Tensor, gather: Optional[Tensor], gather_shift
     if max_rows == 0:
         return y, ab, h
     lib = _lib.load()
+    st = _stream_ptr(a)
+    skp, skb = _splitk_ws(a, st)
     with _on(dev):
         rc = lib.moe_expert_ffn_fwd_train(
             act, a.data_ptr(), a.stride(0), gather.data_ptr() if gather is not None else None, gather_shift,
             w1.data_ptr(), b1.data_ptr() if b1 is not None else None, w2.data_ptr(),
             b2.data_ptr() if b2 is not None else None, group_offsets.data_ptr(), G, n_local, max_rows, M, I,
-            n_gated, ab.data_ptr(), h.data_ptr(), y.data_ptr(), _stream_ptr(a))
+            n_gated, ab.data_ptr(), h.data_ptr(), y.data_ptr(), skp, skb, st)
     _lib.check(rc, "moe_expert_ffn_fwd_train")
     return y, ab, h
 

@@ -32,3 +32,32 @@ def assert_out_close(name, got, want, atol_of_scale=ATOL_OF_SCALE, rtol=RTOL):
     assert not bool(bad.any()), (f"{name}: {int(bad.sum())} of {bad.numel()} elements outside "
                                  f"{atol_of_scale:g} * max|ref| + {rtol:g} * |ref| (max_abs {err:.4e}, max|ref| {scale:.4e})")
     return err, scale
+
+
+class knob:
+    """``with knob("MOE_NO_SKINNY", "1"):`` -- set a diagnostic environment knob of the library for the block.  The library
+    reads its knobs once, so the change (and the restore) is followed by ``ops.reload_knobs()``."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        import os
+        from moe_llava_amd import ops
+        self.prev = os.environ.get(self.name)
+        if self.value is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = str(self.value)
+        ops.reload_knobs()
+        return self
+
+    def __exit__(self, *a):
+        import os
+        from moe_llava_amd import ops
+        if self.prev is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.prev
+        ops.reload_knobs()
+        return False

@@ -10,7 +10,7 @@ import torch
 from oracle import ds_moe_index as ix
 from oracle import ds_moe_literal as lit
 from oracle.expert_mlps import PhiMLPRef, QWenMLPRef, StableLMMLPRef
-from tests._parity import assert_out_close, report as _report
+from tests._parity import assert_out_close, knob, report as _report
 
 pytestmark = pytest.mark.gpu
 
@@ -610,19 +610,13 @@ def test_decode_sizes_skinny_kernel_vs_oracle_and_tiled(kind, M, I, E, S):
     ref, mine, x = _build_pair(kind, M, I, E, (S, 1), 1.0, seed=31, training=False)
     with torch.no_grad():
         out, l_aux, cnt = mine(x.to(DEV))
-        os.environ["MOE_NO_SKINNY"] = "1"
-        try:
+        with knob("MOE_NO_SKINNY", "1"):
             out_tiled, _, _ = mine(x.to(DEV))
-        finally:
-            del os.environ["MOE_NO_SKINNY"]
         # the fc2 launch picks 1 or 2 column groups per block from the launch size; both give the same bits
         forced = []
         for nw in ("1", "2"):
-            os.environ["MOE_SKINNY_NW"] = nw
-            try:
+            with knob("MOE_SKINNY_NW", nw):
                 forced.append(mine(x.to(DEV))[0])
-            finally:
-                del os.environ["MOE_SKINNY_NW"]
     torch.cuda.synchronize()
     assert torch.equal(forced[0], forced[1]) and torch.equal(forced[0], out)
     assert mine.deepspeed_moe.last_routing.max_rows <= 64
@@ -651,11 +645,8 @@ def test_decode_gate_and_routing_in_one_launch_is_bit_identical(S, E, wg_bf16):
     cap = capacity_of(S, E, 2.0, 0)
     seed = 4242 + S
     out, lg, r = ops.block_top2(x, wg, cap, None, seed, True, 0, w1, None, w2, None)
-    os.environ["MOE_NO_GATE_ROUTE_FUSION"] = "1"
-    try:
+    with knob("MOE_NO_GATE_ROUTE_FUSION", "1"):
         out2, lg2, r2 = ops.block_top2(x, wg, cap, None, seed, True, 0, w1, None, w2, None)
-    finally:
-        del os.environ["MOE_NO_GATE_ROUTE_FUSION"]
     torch.cuda.synchronize()
     assert torch.equal(lg, ops.gate_logits(x, wg)) and torch.equal(lg, lg2)
     for name in ("expert_idx", "slot", "weight", "exp_counts", "kept_counts", "expert_offsets", "l_aux"):
@@ -686,18 +677,14 @@ def test_persistent_launch_equals_one_block_per_tile(epilogue):
     N = I if epilogue == 1 else 2 * I                      # output columns (SwiGLU halves the 2I weight rows)
     outs = []
     for env in (None, "1"):
-        if env:
-            os.environ["MOE_NO_PERSIST"] = env
-        try:
+        with knob("MOE_NO_PERSIST", env):
             h = torch.zeros(R, N, dtype=torch.bfloat16, device=DEV)
             rc = lib.moe_grouped_gemm_fwd(epilogue, x.data_ptr(), M, perm.data_ptr(), 1, w1.data_ptr(),
                                           b1.data_ptr() if epilogue == 2 else None, offs.data_ptr(), E, E,
-                                          R, M, N, -1, h.data_ptr(), N, 0, st)
+                                          R, M, N, -1, h.data_ptr(), N, None, 0, 0, st)
             assert rc == 0, lib.moe_last_error()
             torch.cuda.synchronize()
             outs.append(h)
-        finally:
-            os.environ.pop("MOE_NO_PERSIST", None)
     assert torch.equal(outs[0], outs[1])
     # spot check against torch on a few rows of every group
     for e in range(E):

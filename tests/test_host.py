@@ -33,7 +33,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.moe_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.moe_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.moe_splitk_workspace_bytes() == 64 << 20
     assert lib.moe_routing_workspace_bytes(22528, 4) > 0
 
 
@@ -48,8 +49,8 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.moe_gate_logits_fwd(16, 16, 0, 16, 4, 64, 4, 2, 0, None) == -1       # unknown dtype
     assert lib.moe_routing_top2_fwd(16, None, 0, 4, 1, 2, 1, 16, 16, 16, 16, 16, 16, 16, 16, 16, 1 << 20, None) == -2  # E<2
     assert lib.moe_routing_top2_fwd(16, None, 0, 4, 4, 2, 1, 16, 16, 16, 16, 16, 16, 16, 16, 16, 8, None) == -4  # workspace
-    assert lib.moe_expert_ffn_fwd(7, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 64, -1, 16, 16, 0, None) == -1
-    assert lib.moe_expert_ffn_fwd(0, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 100, -1, 16, 16, 1, None) == -2
+    assert lib.moe_expert_ffn_fwd(7, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 64, -1, 16, 16, None, 0, 0, None) == -1
+    assert lib.moe_expert_ffn_fwd(0, 16, 64, None, 0, 16, None, 16, None, 16, 4, 4, 8, 64, 100, -1, 16, 16, None, 0, 1, None) == -2
     assert lib.moe_combine_fwd(16, 16, 16, 16, 16, 4, 64, 3, 16, 0, None) == -2
     # weight-gradient kernel: 32-bit byte offsets inside a group -> more than 4 GiB of rows is refused, not mis-addressed
     assert lib.moe_expert_ffn_bwd(0, 16, 2048, None, 0, 16, 16, 16, 16, 16, 16, 4, 4, 200000, 2048, 5632, -1, 16, 16, None,

@@ -28,6 +28,7 @@ ap.add_argument("--skew", type=int, default=1)
 ap.add_argument("--sorted", type=int, default=1, help="gather rows in token order (as the routing kernel produces them)")
 ap.add_argument("--cold", type=int, default=1, help="weight copies cycled per call (cold weights for decode-size runs)")
 ap.add_argument("--gelu", type=int, default=0, help="fc1 = Phi form: W1 [E, I, M] + bias, gelu_new epilogue (default: gated SwiGLU, W1 [E, 2I, M])")
+ap.add_argument("--splitk", type=int, default=1, help="1: pass a split-K workspace (product behaviour), 0: none")
 ap.add_argument("--pad", type=int, default=0, help="pad leading dims of x / h (and the w buffers, for -DGEMM_EXP_LDW_PAD builds)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -51,18 +52,21 @@ perm = (torch.arange(R, device=dev) if a.sorted else torch.randperm(R, device=de
 h = torch.empty(R, I + P, dtype=torch.bfloat16, device=dev)
 y = torch.empty(R, M, dtype=torch.bfloat16, device=dev)
 st = torch.cuda.current_stream().cuda_stream
+SKB = 256 * 256 * 256 * 4 if a.splitk else 0
+skws = torch.empty(max(SKB, 16), dtype=torch.uint8, device=dev)
+SKP = skws.data_ptr() if a.splitk else None
 libs = {v: load(v) for v in a.variants}
 
 def fc1(lib):
     w1 = w1s[calls[0] % a.cold]; calls[0] += 1
     if a.gelu:
-        rc = lib.moe_grouped_gemm_fwd(2, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), b1.data_ptr(), offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, 0, st)
+        rc = lib.moe_grouped_gemm_fwd(2, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), b1.data_ptr(), offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, SKP, SKB, 0, st)
     else:
-        rc = lib.moe_grouped_gemm_fwd(1, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), None, offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, 0, st)
+        rc = lib.moe_grouped_gemm_fwd(1, x.data_ptr(), M + P, perm.data_ptr(), 1, w1.data_ptr(), None, offs.data_ptr(), E, E, R, M, I, -1, h.data_ptr(), I + P, SKP, SKB, 0, st)
     assert rc == 0, lib.moe_last_error()
 def fc2(lib):
     w2 = w2s[calls[1] % a.cold]; calls[1] += 1
-    rc = lib.moe_grouped_gemm_fwd(0, h.data_ptr(), I + P, None, 0, w2.data_ptr(), None, offs.data_ptr(), E, E, R, I, M, -1, y.data_ptr(), M, 0, st)
+    rc = lib.moe_grouped_gemm_fwd(0, h.data_ptr(), I + P, None, 0, w2.data_ptr(), None, offs.data_ptr(), E, E, R, I, M, -1, y.data_ptr(), M, SKP, SKB, 0, st)
     assert rc == 0, lib.moe_last_error()
 
 shapes = {"fc1": (fc1, 2.0 * R * N1 * M), "fc2": (fc2, 2.0 * R * M * I)}
