@@ -171,12 +171,18 @@ def run_other_configs(device, fence):
         res[f"config{cid}"] = d
         del layers, x, r
         torch.cuda.empty_cache()
-    # decode steps: StableLM block in eval mode (eval_capacity_factor 2.0), 12 layers' weights cycled
+    res.update(run_decode(device, fence, (1, 32)))
+    return res
+
+
+def run_decode(device, fence, sizes, steps=120):
+    """Decode steps: StableLM block in eval mode (eval_capacity_factor 2.0), 12 layers' weights cycled."""
+    res = {}
     cfg = CONFIGS[1]
     layers = build_layers(cfg, device, 1, 0, seed=5000, training=False)
-    for S in (1, 32):
+    for S in sizes:
         x = make_inputs(cfg, 1, device, seed=9)[:, :S].reshape(S, 1, cfg["M"]).contiguous()
-        sec = time_steps(layers, x, 120, 24, fence) / 120
+        sec = time_steps(layers, x, steps, 24, fence) / steps
         act = 0
         for m in layers:
             with torch.no_grad():
@@ -184,7 +190,7 @@ def run_other_configs(device, fence):
             act += int((m.deepspeed_moe.exp_counts > 0).sum())
         d = summarize(cfg, S, 2.0 * S, act / len(layers), sec)
         d.update(workload=f"decode step, StableLM-1.6B-4e block, S = {S} tokens, eval capacity (idle experts' weights are "
-                          f"not part of the algorithmic bytes)", layers_cycled=cfg["layers"], steps=120, warmup=24,
+                          f"not part of the algorithmic bytes)", layers_cycled=cfg["layers"], steps=steps, warmup=24,
                  active_experts_mean=act / len(layers))
         res[f"decode_S{S}"] = d
     del layers
@@ -288,11 +294,19 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (per-GPU shape)")
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (default: the config's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="fp16 = the reference's inference loader dtype")
+    ap.add_argument("--decode", type=int, default=0, metavar="S",
+                    help="time decode steps of S tokens instead (StableLM block, eval capacity, 12 layers' weights cycled; "
+                         "the other_configs decode_S<S> entry on its own, for profiling) and print its summary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the informational forward+backward timing")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs object")
     args = ap.parse_args()
 
+    if args.decode:
+        device = torch.device("cuda", 0)
+        torch.cuda.set_device(device)
+        print(json.dumps(run_decode(device, torch.cuda.synchronize, (args.decode,), steps=max(args.steps, 120))), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process has not touched the GPU (no HIP call, no library load) and never
         # will -- it starts the N ranks as children of torch.distributed.run, waits, and exits with their code

@@ -197,7 +197,8 @@ int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gathe
 /* Split-K tail of the grouped GEMM launches (ABI v8; no counterpart in the reference, whose expert GEMMs are cuBLAS
  * calls).  A launch is a list of tiles that each XCD's 32 CUs work through in rounds; the last round of an XCD is
  * usually partial (config 3's fc2: 4.3 rounds run as 5).  Given a workspace, the Rm < 32 tiles of that round are cut
- * along K into floor(32 / Rm) pieces (at most MOE_SPLITK, default 8; a piece is at least 4 K slices of 64) that leave
+ * along K into floor(32 / Rm) pieces (at most MOE_SPLITK, default 8; a piece is at least MOE_SPLITK_MIN K slices of 64,
+ * default 24: below that the fix-up costs more than the idle CUs it fills; persistent launches are never split) that leave
  * their fp32 accumulators in the workspace, and a fix-up launch right behind adds each tile's pieces IN K ORDER and runs
  * the epilogue: no atomics, results bit-identical from call to call.  A split tile differs from a whole one only through
  * the fp32 summation order over K, so two launches that cut their lists differently (another row count, another
@@ -206,7 +207,7 @@ int moe_expert_ffn_fwd(int act, const void *a, int64_t lda, const int32_t *gathe
 size_t moe_splitk_workspace_bytes(void);
 
 /* moe_reload_knobs: the library reads its diagnostic environment knobs (MOE_GEMM_TILE, MOE_GEMM_ORDER, MOE_NO_PERSIST,
- * MOE_NO_SKINNY, MOE_NO_GATE_ROUTE_FUSION, MOE_SKINNY_NW, MOE_SKINNY_KS, MOE_SPLITK) once, at first use; a test or
+ * MOE_NO_SKINNY, MOE_NO_GATE_ROUTE_FUSION, MOE_SKINNY_NW, MOE_SKINNY_KS, MOE_SPLITK, MOE_SPLITK_MIN, MOE_GEMM_RS) once, at first use; a test or
  * tuning tool that changes one of them afterwards calls this to have them read again. */
 void moe_reload_knobs(void);
 
@@ -275,6 +276,24 @@ int moe_block_top2_fwd_dseed(const void *x, const void *wg, int wg_dtype, float 
                              void *routing_ws, size_t routing_ws_bytes, const void *w1, const void *b1, const void *w2,
                              const void *b2, void *h_ws, void *y, void *out, void *splitk_ws, size_t splitk_ws_bytes,
                              int dtype, void *stream);
+
+/* moe_block_top2_fwd_args (ABI v8): moe_block_top2_fwd / moe_block_top2_fwd_dseed with the arguments in one block of
+ * memory, same names and meanings (noise_seed_dev != NULL selects the device-side seed form; noise must then be NULL).
+ * For callers that repeat a step (the generate loop, moellava/serve/cli.py:102-111): they keep the block and rewrite the
+ * fields that change.  The library reads the block during the call only. */
+typedef struct moe_block_top2_args {
+    const void *x; const void *wg; int wg_dtype; float *logits; const float *noise; uint64_t noise_seed;
+    uint64_t *noise_seed_dev;
+    int S, M, E, I, act, capacity, drop_tokens, n_gated;
+    int32_t *expert_idx; int32_t *slot; float *weight; int64_t *exp_counts; int32_t *kept_counts;
+    int32_t *expert_offsets; int32_t *perm; float *l_aux;
+    void *routing_ws; size_t routing_ws_bytes;
+    const void *w1; const void *b1; const void *w2; const void *b2;
+    void *h_ws; void *y; void *out;
+    void *splitk_ws; size_t splitk_ws_bytes;
+    int dtype; void *stream;
+} moe_block_top2_args;
+int moe_block_top2_fwd_args(const moe_block_top2_args *args);
 
 /* ---- backward ---------------------------------------------------------------
  * Upstream has no hand-written backward: torch autograd differentiates top2gating, the two einsums, _AllToAll

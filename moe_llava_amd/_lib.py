@@ -57,6 +57,7 @@ _SIGNATURES = [
      [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    ("moe_block_top2_fwd_args", c_int, [c_void_p]),
     # ---- backward ----
     ("moe_expert_ffn_fwd_train", c_int,
      [c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -76,6 +77,23 @@ _SIGNATURES = [
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
       c_uint64, c_void_p]),
 ]
+
+class BlockTop2Args(ctypes.Structure):
+    """``moe_block_top2_args`` of include/moe_gfx950.h (field for field)."""
+    _fields_ = [
+        ("x", c_void_p), ("wg", c_void_p), ("wg_dtype", c_int), ("logits", c_void_p), ("noise", c_void_p),
+        ("noise_seed", c_uint64), ("noise_seed_dev", c_void_p),
+        ("S", c_int), ("M", c_int), ("E", c_int), ("I", c_int), ("act", c_int), ("capacity", c_int),
+        ("drop_tokens", c_int), ("n_gated", c_int),
+        ("expert_idx", c_void_p), ("slot", c_void_p), ("weight", c_void_p), ("exp_counts", c_void_p),
+        ("kept_counts", c_void_p), ("expert_offsets", c_void_p), ("perm", c_void_p), ("l_aux", c_void_p),
+        ("routing_ws", c_void_p), ("routing_ws_bytes", c_size_t),
+        ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
+        ("h_ws", c_void_p), ("y", c_void_p), ("out", c_void_p),
+        ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_size_t),
+        ("dtype", c_int), ("stream", c_void_p),
+    ]
+
 
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 

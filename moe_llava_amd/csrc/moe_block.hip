@@ -68,3 +68,15 @@ extern "C" int moe_block_top2_fwd_dseed(const void *x, const void *wg, int wg_dt
                       expert_idx, slot, weight, exp_counts, kept_counts, expert_offsets, perm, l_aux, routing_ws,
                       routing_ws_bytes, w1, b1, w2, b2, h_ws, y, out, splitk_ws, splitk_ws_bytes, stream);
 }
+
+// The same call with its arguments in one block of memory (ABI v8): a caller that repeats a decode step keeps the block and
+// rewrites the few fields that change (x, the seed, out), instead of marshalling 35 arguments per call -- at S = 1 the
+// host side of the call is what bounds the step.  noise_seed_dev != NULL selects the device-side seed form.
+extern "C" int moe_block_top2_fwd_args(const moe_block_top2_args *a) {
+    if (!a) return fail(MOE_ERR_ARG, "moe_block_top2_fwd_args: null argument block");
+    if (a->noise_seed_dev && a->noise) return fail(MOE_ERR_ARG, "moe_block_top2_fwd_args: noise tensor and device-side seed are exclusive");
+    return block_top2(a->x, a->dtype, a->wg, a->wg_dtype, a->logits, a->noise, a->noise_seed, a->noise_seed_dev, a->S, a->M,
+                      a->E, a->I, a->act, a->capacity, a->drop_tokens, a->n_gated, a->expert_idx, a->slot, a->weight,
+                      a->exp_counts, a->kept_counts, a->expert_offsets, a->perm, a->l_aux, a->routing_ws, a->routing_ws_bytes,
+                      a->w1, a->b1, a->w2, a->b2, a->h_ws, a->y, a->out, a->splitk_ws, a->splitk_ws_bytes, a->stream);
+}

@@ -18,11 +18,13 @@ int fail(int code, const char *fmt, ...);
 struct Knobs {
     int tile_bm, tile_bnw;     // MOE_GEMM_TILE="bm,bnw": force a tile of the grouped GEMM (0 = the host rule)
     int order;                 // MOE_GEMM_ORDER: 0 super-rows, 1 group-major, -1 = rule
+    int rs;                    // MOE_GEMM_RS: force the super-row height of the 256-row tiles (0 = rule)
     bool no_persist;           // MOE_NO_PERSIST
     bool no_skinny;            // MOE_NO_SKINNY: decode-size launches through the tiled kernel
     bool no_gate_route_fusion; // MOE_NO_GATE_ROUTE_FUSION
     int skinny_nw, skinny_ks;  // MOE_SKINNY_NW / MOE_SKINNY_KS (0 = rule)
     int splitk;                // MOE_SPLITK: largest split factor of the split-K tail (0 or 1 = off; default 8)
+    int splitk_min;            // MOE_SPLITK_MIN: fewest K slices per piece (0 = the default, 24)
 };
 const Knobs &knobs();
 
@@ -315,6 +317,7 @@ struct GemmParams {
     int dtype;          // DT_BF16 / DT_F16: element type of a, w, bias, out (16-bit raw in the pointers above)
     float *splitk_ws;   // split-K tail (moe_gemm.hip): fp32 accumulators of the K pieces; NULL = no split
     int splitk_max;     // largest split factor (<= 1: tiles are never split)
+    int splitk_min_slices;  // a K piece covers at least this many 64-wide K slices
 };
 
 // Decode-size launches (moe_gemv.hip): every group has at most SKINNY_MAX_ROWS rows.

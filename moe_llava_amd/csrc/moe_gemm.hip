@@ -128,8 +128,15 @@ __device__ __forceinline__ void wait_vm_barrier() {
 
 constexpr int CUS_PER_XCD = 32;    // MI355X: 256 CUs in 8 XCDs
 constexpr int SPLITK_SLOTS = 8 * CUS_PER_XCD;  // workspace slots: at most one piece per CU in the split round
-constexpr int SPLITK_MIN_SLICES = 4;  // a piece covers at least this many K slices (below that its prologue and its
-                                      // partial-tile store cost more than the idle CU they fill)
+constexpr int SPLITK_MAX = 8;         // largest split factor (MOE_SPLITK lowers it)
+#ifndef SPLITK_MIN_SLICES_DEF
+#define SPLITK_MIN_SLICES_DEF 24
+#endif
+// A piece covers at least this many K slices.  Measured (profiles/r03/splitk_*): the fix-up launch costs 5-15 us (the
+// pieces' fp32 tiles written and read back: 27-61 MB), so cutting the last round only pays when a tile is long: config 3's
+// fc2 (K = 10240, 160 slices, 3 pieces per tile) -13 %; K = 2048 launches (32 slices: fc1 of configs 1, 4) gained 5-7 us
+// in the GEMM and lost 11-14 us to the fix-up, so they are no longer split.
+constexpr int SPLITK_MIN_SLICES = SPLITK_MIN_SLICES_DEF;   // default of GemmParams::splitk_min_slices (MOE_SPLITK_MIN)
 
 // Work list of one grouped-GEMM launch, derived per block from the device-side group sizes (scalar work).
 // Shared by grouped_gemm_kernel and splitk_fixup_kernel: both must cut the list the same way.
@@ -144,7 +151,9 @@ struct TileSched {
         for (int g = 0; g < p.G; ++g) rt += (p.group_offsets[g + 1] - p.group_offsets[g] + BM - 1) / BM;
         RT = rt;
         T = rt * p.col_tiles;
-        int m = p.splitk_max < nk / SPLITK_MIN_SLICES ? p.splitk_max : nk / SPLITK_MIN_SLICES;
+        const int per = p.splitk_min_slices > 0 ? p.splitk_min_slices : 1;
+        int m = p.splitk_max < nk / per ? p.splitk_max : nk / per;
+        if (m > SPLITK_MAX) m = SPLITK_MAX;
         smax = m < 1 ? 1 : m;
     }
     // the eighth of the list that XCD x takes: [start, start + n)
@@ -723,42 +732,73 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
 
 // Fix-up of the split-K tail: adds the K pieces of every split tile in K order (fixed order: bit-reproducible) and runs
 // the epilogue of grouped_gemm_kernel on the sums -- same bias / rounding / activation sequence, so a split tile differs
-// from a whole one only through the fp32 summation order over K.  One block = one (XCD x, tile t of its last round, part)
-// triple; a wave takes (row fragment, output column fragment) pairs, reads the pieces' 1-KiB fragment blocks (coalesced,
-// in the (lane, register) order the pieces were stored in) and stores 4 consecutive outputs per lane.
+// from a whole one only through the fp32 summation order over K.  A fixed grid of FIXUP_BLOCKS blocks of 16 waves: every
+// block re-derives the launch's cut (which XCDs split their last round, how many tiles, how many pieces: scalar work), and
+// its waves take (split tile, row fragment, output column fragment) items with the stride of all the grid's waves; a wave
+// reads the pieces' 1-KiB fragment blocks (coalesced, in the (lane, register) order the pieces were stored in) and
+// stores 4 consecutive outputs per lane.  When nothing was split the blocks exit after the scalar part (~2.5 us).
 // HBM-bound: s * BM * BNW * 4 bytes read per split tile (at most 128 split tiles per launch).
-constexpr int FIXUP_PARTS = 8;
+constexpr int FIXUP_BLOCKS = 256, FIXUP_THREADS = 1024;
 template <int DT, int EPI, int BM, int BNW>
-__global__ __launch_bounds__(256) void splitk_fixup_kernel(const GemmParams p) {
+__global__ __launch_bounds__(FIXUP_THREADS) void splitk_fixup_kernel(const GemmParams p) {
     using T = Tile<EPI, BM, BNW>;
     typedef Elt<DT> E;
     constexpr int NC = T::NC, NF = T::NF, WNT = T::WNT;
     constexpr int TF = BM / 16;    // row fragments of a tile
     constexpr int OCF = NC / 16;   // output column fragments of a tile
     constexpr int WCF = BNW / 16;  // W-row fragments (columns of the accumulator tile)
-    const int part = (int)blockIdx.x % FIXUP_PARTS;
-    const int tl = ((int)blockIdx.x / FIXUP_PARTS) % (CUS_PER_XCD / 2);
-    const int x = (int)blockIdx.x / (FIXUP_PARTS * (CUS_PER_XCD / 2));
+    constexpr int ITEMS = TF * OCF;
     const TileSched<BM> sch(p, p.K / BK);
-    int start, n, full, rm, s;
-    sch.chunk(x, start, n);
-    sch.tail(n, full, rm, s);
-    if (s < 2 || tl >= rm) return;  // uniform per block: this XCD's last round was not split, or has fewer tiles
-    int ct, row_begin, row_end, expert;
-    sch.tile(p, start + full + tl, ct, row_begin, row_end, expert);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // split tiles of the launch, XCD by XCD: first[x] = index of XCD x's first split tile in the list of all of them
+    int first[9], x_start[8], x_full[8], x_rm[8], x_s[8];
+    first[0] = 0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        int n;
+        sch.chunk(x, x_start[x], n);
+        sch.tail(n, x_full[x], x_rm[x], x_s[x]);
+        first[x + 1] = first[x] + (x_s[x] >= 2 ? x_rm[x] : 0);
+    }
+    const int n_items = first[8] * ITEMS;
+    if (n_items == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int gwave = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (FIXUP_THREADS / 64) + ((int)threadIdx.x >> 6));
     const int fr = lane & 15, fq = lane >> 4;
-    // piece q of this tile sits in slot x * 32 + q * rm + tl (TileSched::decode)
-    const float *ws0 = p.splitk_ws + (size_t)(x * CUS_PER_XCD + tl) * (size_t)(BM * BNW);
-    const size_t piece_stride = (size_t)rm * (size_t)(BM * BNW);
-    const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
-    auto frag_sum = [&](int rf, int wf) {
-        const float *src = ws0 + ((size_t)(rf * WCF + wf) * 64 + lane) * 4;
-        f32x4_t v = *reinterpret_cast<const f32x4_t *>(src);
-        for (int q = 1; q < s; ++q) v += *reinterpret_cast<const f32x4_t *>(src + q * piece_stride);
-        return v;
-    };
-    for (int item = part * 4 + wave; item < TF * OCF; item += FIXUP_PARTS * 4) {
+    int cur_tile = -1, ct = 0, row_begin = 0, row_end = 0, expert = 0, rm = 1, s = 1;
+    const float *ws0 = nullptr;
+    for (int it = gwave; it < n_items; it += FIXUP_BLOCKS * (FIXUP_THREADS / 64)) {
+        const int ti = it / ITEMS, item = it - ti * ITEMS;
+        if (ti != cur_tile) {  // wave-uniform: locate the tile (scalar work)
+            cur_tile = ti;
+            int x = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q)
+                if (ti >= first[q]) x = q;
+            int xs = 0, xf = 0, tl = ti;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q == x) { xs = x_start[q]; xf = x_full[q]; rm = x_rm[q]; s = x_s[q]; tl = ti - first[q]; }
+            sch.tile(p, xs + xf + tl, ct, row_begin, row_end, expert);
+            // piece q of this tile sits in slot x * 32 + q * rm + tl (TileSched::decode)
+            ws0 = p.splitk_ws + (size_t)(x * CUS_PER_XCD + tl) * (size_t)(BM * BNW);
+        }
+        const size_t piece_stride = (size_t)rm * (size_t)(BM * BNW);
+        const bf16_t *bias = p.bias ? p.bias + (long long)expert * p.bias_expert_stride : nullptr;
+        // all pieces of a fragment are requested before the first is used (one memory round trip per fragment, not s);
+        // the adds stay in K order
+        static_assert(SPLITK_MAX <= 8, "frag_sum holds at most 8 pieces in flight");
+        auto frag_sum = [&](int rf, int wf) {
+            const float *src = ws0 + ((size_t)(rf * WCF + wf) * 64 + lane) * 4;
+            f32x4_t v[SPLITK_MAX];
+#pragma unroll
+            for (int q = 0; q < SPLITK_MAX; ++q)
+                if (q < s) v[q] = *reinterpret_cast<const f32x4_t *>(src + q * piece_stride);
+            f32x4_t r = v[0];
+#pragma unroll
+            for (int q = 1; q < SPLITK_MAX; ++q)
+                if (q < s) r += v[q];
+            return r;
+        };
         const int rf = item / OCF, cf = item % OCF;
         const int prow = row_begin + rf * 16 + fr;
         uint2 o;
@@ -847,6 +887,7 @@ static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     // super-row height: 4 row tiles (an XCD's 32 CUs then work on 4 x 8 tiles); launches with few column tiles (fc2 of
     // config 2: 8) measured 2 % faster with 3 (same-process A/B: 811 -> 793 us; fc1 with 44 column tiles 0.7 % slower)
     p.rs = GEMM_RS > 0 ? GEMM_RS : (p.col_tiles <= 8 ? 3 : 4);
+    if (kn.rs > 0) p.rs = kn.rs;   // MOE_GEMM_RS: experiments
     // small row tiles = few rows per group = weight streaming: group-major tile order (see TileSched::tile);
     // MOE_GEMM_ORDER=0/1 forces super-rows / group-major for A/B runs
     if (BM < 256) p.rs = 0;
@@ -857,7 +898,16 @@ static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     // Split-K tail (see the kernel): needs the caller's workspace, one BM x BNW fp32 slot per CU; the backward epilogues
     // that read pre-activations in their store phase are never split.
     constexpr bool CAN_SPLIT = EPI == EPI_PLAIN || EPI == EPI_SWIGLU || EPI == EPI_GELU_NEW;
-    const bool split = CAN_SPLIT && p.splitk_ws != nullptr && p.splitk_max >= 2 && p.K / BK >= 2 * SPLITK_MIN_SLICES;
+    // persistent launches (>= 16 rounds) are not split either: their blocks drift apart over the rounds and the last round is
+    // no longer a step in the launch's time (config 3's fc1, 17.2 rounds: the GEMM gained 1 %, the fix-up cost 15 us)
+    const bool persistent = (GEMM_PERSIST && BM == 256 && BNW == 256 && tiles >= 4096 && !kn.no_persist) ||
+                            (BM < 256 && Tile<EPI, BM, BNW>::OVERLAP && tiles > 256 && !kn.no_persist);
+    // ... and only launches whose tiles are long (K >= 4096) and that fill the chip at least once: the fix-up launch costs
+    // ~4.6 us even when the device finds nothing to split (config 1's fc2: 224 tiles of 57 us), 12-20 us when it runs.
+    // MOE_SPLITK_MIN (tests, sweeps) lifts the two host-side conditions.
+    const bool forced = kn.splitk_min > 0;
+    const bool split = CAN_SPLIT && !persistent && p.splitk_ws != nullptr && p.splitk_max >= 2 &&
+                       p.K / BK >= 2 * p.splitk_min_slices && (forced || (p.K / BK >= 64 && tiles >= 8 * CUS_PER_XCD));
     if (!split) { p.splitk_ws = nullptr; p.splitk_max = 1; }
     // one block per work item: every XCD's sequence is at most ceil(tiles / 8) whole tiles (+ up to 32 pieces in place of
     // its last partial round); the grid is a multiple of 8 so that block b's XCD is b & 7 whatever the size
@@ -869,15 +919,13 @@ static int launch_tile(GemmParams &p, int max_rows_or_neg, hipStream_t st) {
     // blocks, could no longer interleave with a second stream's launch, so they keep one block per tile)
     // Small row tiles, -DGEMM_OVERLAP_SMALL=1 builds only: launches of more than one round run persistent too, with the
     // next tile's pointers and first slice under the epilogue.
-    if (GEMM_PERSIST && BM == 256 && BNW == 256 && tiles >= 4096 && !kn.no_persist) grid = 8 * CUS_PER_XCD;
-    if (BM < 256 && Tile<EPI, BM, BNW>::OVERLAP && tiles > 256 && !kn.no_persist) grid = 8 * CUS_PER_XCD;
+    if (persistent) grid = 8 * CUS_PER_XCD;
     hipLaunchKernelGGL((grouped_gemm_kernel<DT, EPI, BM, BNW>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, p);
     int rc = check_launch("grouped_gemm_kernel");
     if (rc || !split) return rc;
     if constexpr (CAN_SPLIT) {
-        // fix-up of the split tiles: one block per (XCD, tile of its last round, part of the tile); blocks whose tile was
-        // not split (the decision is the device's) exit at once
-        hipLaunchKernelGGL((splitk_fixup_kernel<DT, EPI, BM, BNW>), dim3(8 * CUS_PER_XCD / 2 * FIXUP_PARTS), dim3(256), 0, st, p);
+        // fix-up of the split tiles (whether anything was split is the device's decision: the blocks exit when not)
+        hipLaunchKernelGGL((splitk_fixup_kernel<DT, EPI, BM, BNW>), dim3(FIXUP_BLOCKS), dim3(FIXUP_THREADS), 0, st, p);
         rc = check_launch("splitk_fixup_kernel");
     }
     return rc;
@@ -980,6 +1028,7 @@ static int grouped_gemm_launch(const char *fn, int epilogue, const void *a, int6
         p.splitk_ws = (float *)splitk_ws;
         p.splitk_max = knobs().splitk;
     }
+    p.splitk_min_slices = knobs().splitk_min > 0 ? knobs().splitk_min : SPLITK_MIN_SLICES;
     if (dtype == MOE_DTYPE_F16) {  // forward epilogues only: the backward entry points are bf16
         switch (epilogue) {
             case MOE_EPI_SWIGLU: return launch_gemm<DT_F16, EPI_SWIGLU>(p, max_rows, t, st);

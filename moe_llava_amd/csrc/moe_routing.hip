@@ -48,13 +48,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 template <int EMAX, int R, bool WG16, int DT, bool JIT = false>
 __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const void *__restrict__ wg,
                                           float *__restrict__ logits, int S, int M, int E, int row0, int lane,
-                                          unsigned long long jitter_seed = 0ull) {
+                                          unsigned long long jitter_seed = 0ull, int e_sub = 0, int e_step = 1) {
+    // e_sub / e_step: this wave computes the experts e with e % e_step == e_sub only (the decode kernel spreads a row
+    // group's experts over several waves; every (row, expert) chain is the same whichever wave runs it)
     float acc[R][EMAX];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) acc[r][e] = 0.f;
 
+#ifndef GATE_UNROLL
+#define GATE_UNROLL 1
+#endif
+#pragma unroll GATE_UNROLL
     for (int m0 = lane * 8; m0 < M; m0 += 64 * 8) {
         float xf[R][8];
 #pragma unroll
@@ -72,7 +78,7 @@ __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const vo
         }
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) {
-            if (e < E) {
+            if (e < E && e % e_step == e_sub) {
                 float w[8];
                 if (WG16) {
                     unpack8_t<DT>(*reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(wg) + (size_t)e * M + m0), w);
@@ -93,7 +99,7 @@ __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const vo
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) {
-            if (e < E) {
+            if (e < E && e % e_step == e_sub) {
                 const float v = wave_sum(acc[r][e]);
                 if (lane == 0 && row0 + r < S) logits[(size_t)(row0 + r) * E + e] = v;
             }
@@ -393,18 +399,29 @@ __device__ __forceinline__ void route_fused_body(
         unsigned long long nx = seed * 6364136223846793005ull + 1442695040888963407ull;  // next key of the Philox stream
         *seed_dev = nx ? nx : 1ull;                                                          // 0 means "no noise"
     }
-    // exclusive scan over (chunk, wave) per (choice, expert); thread q = choice*E + e
-    if (tid < 2 * E) {
-        const int ch = tid / E, e = tid % E;
-        int run = 0;
-        for (int c = 0; c < nchunk; ++c)
-            for (int w = 0; w < NW; ++w) {
-                const int v = wcnt[c][ch][w][e];
-                wcnt[c][ch][w][e] = run;
-                run += v;
-            }
-        if (ch == 0) s_n1[e] = run;
-        else s_off[e] = run;  // n2, parked until thread 0 turns it into offsets
+    // exclusive scan over (chunk, wave) per (choice, expert), and the per-expert gate sums: one wave per (choice, expert)
+    // pair, lane = chunk * NW + wave index (FUSED_T * NW = 64 lanes), a shuffle scan instead of a 64-step serial loop in
+    // one thread (that loop and the fp64 gate sums in thread 0 were ~10 us of the kernel's 19 at S = 2432)
+    static_assert(FUSED_T * NW == 64, "one lane per (chunk, wave) entry");
+    __shared__ double s_gs[EMAX];
+    for (int q = wave; q < 2 * E; q += NW) {
+        const int ch = q / E, e = q - ch * E;
+        const int c = lane / NW, w = lane % NW;
+        const int v = c < nchunk ? wcnt[c][ch][w][e] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (c < nchunk) wcnt[c][ch][w][e] = incl - v;
+        const int total = __shfl(incl, 63, 64);
+        if (ch == 0) {
+            const double gs = wave_sum_d(c < nchunk ? (double)wsum[c][w][e] : 0.0);
+            if (lane == 0) { s_n1[e] = total; s_gs[e] = gs; }
+        } else if (lane == 0) {
+            s_off[e] = total;  // n2, parked until thread 0 turns it into offsets
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -426,10 +443,7 @@ __device__ __forceinline__ void route_fused_body(
             expert_offsets[e] = off;
             s_off[e] = off;
             off += k1 + k2;
-            double gs = 0.0;
-            for (int c = 0; c < nchunk; ++c)
-                for (int w = 0; w < NW; ++w) gs += (double)wsum[c][w][e];
-            const float me = (float)gs / fS;
+            const float me = (float)s_gs[e] / fS;
             const float ce = (float)n1 / fS;
             lsum += me * ce;
         }
@@ -481,7 +495,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void gate_route_fused_kernel(
     int *__restrict__ expert_idx, int *__restrict__ slot, float *__restrict__ weight, long long *__restrict__ exp_counts,
     int *__restrict__ kept_counts, int *__restrict__ expert_offsets, int *__restrict__ perm, float *__restrict__ l_aux) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave * 4 < S) gate_rows<EMAX, 4, WG16, DT>(x, wg, logits, S, M, E, wave * 4, lane);
+    // 16 waves, row groups of 4 rows: with fewer than 16 row groups the experts of a group are spread over 16 / groups
+    // waves (S = 1: four waves, one expert each), so that the cold gate weight is fetched through several waves' loads
+    // at once.  Each (row, expert) sum is the same fmaf chain + butterfly whichever wave computes it: logits stay
+    // bit-identical to gate_logits_kernel's.
+    const int nrg = (S + 3) >> 2;
+    int wpr = (FUSED_THREADS / 64) / nrg;
+    if (wpr > E) wpr = E;
+    if (wpr < 1) wpr = 1;
+    if (wave < nrg * wpr) gate_rows<EMAX, 4, WG16, DT>(x, wg, logits, S, M, E, (wave / wpr) * 4, lane, 0ull, wave % wpr, wpr);
     __threadfence_block();
     __syncthreads();  // the block's own global writes are visible to it after the barrier
     route_fused_body<EMAX>(logits, noise, seed, seed_dev, S, E, capacity, drop_tokens, expert_idx, slot, weight, exp_counts,
@@ -626,6 +648,7 @@ void read_knobs(Knobs &k) {
         int bm = 0, bnw = 0;
         if (sscanf(env, "%d,%d", &bm, &bnw) == 2) { k.tile_bm = bm; k.tile_bnw = bnw; }
     }
+    if (const char *env = getenv("MOE_GEMM_RS")) k.rs = atoi(env);
     if (const char *env = getenv("MOE_GEMM_ORDER")) k.order = env[0] == '0' ? 0 : env[0] == '1' ? 1 : -1;
     k.no_persist = getenv("MOE_NO_PERSIST") != nullptr;
     k.no_skinny = getenv("MOE_NO_SKINNY") != nullptr;
@@ -633,6 +656,7 @@ void read_knobs(Knobs &k) {
     if (const char *env = getenv("MOE_SKINNY_NW")) k.skinny_nw = atoi(env);
     if (const char *env = getenv("MOE_SKINNY_KS")) k.skinny_ks = atoi(env);
     if (const char *env = getenv("MOE_SPLITK")) k.splitk = atoi(env);
+    if (const char *env = getenv("MOE_SPLITK_MIN")) k.splitk_min = atoi(env);
 }
 }  // namespace
 const Knobs &knobs() {

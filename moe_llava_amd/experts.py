@@ -227,6 +227,35 @@ class Experts(nn.Module):
         self._ptrs = [(p.data_ptr(), tuple(p.shape)) for p in self._params(specs)]
         return specs[0].act, w1, b1, w2, b2
 
+    def packed_unchanged(self):
+        """The tuple ``packed()`` returned last time if nothing it depends on has moved since (same Parameter objects at
+        the same addresses with the same leading size), else None -- the cheap check of the decode fast path, which
+        is host-bound.  Experts whose parameters live in somebody else's buffer, or with a RePaMLP mask, always answer
+        None (they need the full ``packed()`` on every call)."""
+        fast = self.__dict__.get("_fast")
+        if fast is None:
+            return None
+        for d, name, prm, ptr, n0 in fast[0]:
+            if d.get(name) is not prm or prm.data_ptr() != ptr or prm.shape[0] != n0:
+                self.__dict__["_fast"] = None
+                return None
+        return fast[1]
+
+    def _remember_fast(self, specs, result) -> None:
+        """Called by the decode fast path after a full ``packed()``: record what ``packed_unchanged`` compares."""
+        if self._external or specs[0].n_gated >= 0 or any(hasattr(e, "mask") for e in self.deepspeed_experts):
+            self.__dict__["_fast"] = None
+            return
+        chk = []
+        for sp in specs:
+            for lin in sp.fc1 + [sp.fc2]:
+                d = lin._parameters
+                for name in ("weight", "bias"):
+                    prm = d.get(name)
+                    if prm is not None:
+                        chk.append((d, name, prm, prm.data_ptr(), prm.shape[0]))
+        self.__dict__["_fast"] = (chk, result)
+
     def _views(self, specs, pk):
         """(nn.Linear, weight view, bias view | None) of every projection in the packed buffers ``pk``."""
         I = specs[0].fc1[0].weight.shape[0]

@@ -5,6 +5,7 @@ expert GEMM; the Python here only orchestrates launches (and, for ``ep_size > 1`
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import math
@@ -136,6 +137,90 @@ class TopKGate(nn.Module):
         return ops.routing_top1(lg, cap, used_token, self.use_rts, uni, rseed, noise, nseed, self.drop_tokens)
 
 
+DECODE_MAX_TOKENS = 64      # calls of at most this many tokens take the cached decode plan (the GEMV-style kernels' range)
+
+
+class _DecodePlan:
+    """Everything one decode-size forward (S <= 64 tokens, one GPU, top-2, no grad) needs, built once per
+    (S, dtype, device, stream, training flag) and reused: the routing arena, logits and the h / y workspace, and the
+    argument block of ``moe_block_top2_fwd_args`` with every constant field filled in.  A call then rewrites three
+    fields (x, the Gumbel seed, out) and makes ONE ctypes call with ONE argument: at S = 1 the kernels take ~45 us and
+    the host side of the call was what bounded the step (profiles/r03/decode_host_*).
+
+    The buffers are REUSED: ``l_aux``, ``exp_counts``, ``gate.last_logits`` and ``last_routing`` of such a call are views
+    that the module's next decode-size call overwrites (clone what must survive a later call); the output is a
+    fresh tensor every time."""
+
+    __slots__ = ("args", "ref", "routing", "logits", "hy", "packed", "S", "M", "cap", "sampling", "fn", "l_aux", "exp_counts",
+                 "dtype", "dev")
+
+    def __init__(self, layer: "MOELayer", x: Tensor, packed, st: int):
+        from . import _lib
+        gate, experts = layer.gate, layer.experts
+        act, w1, b1, w2, b2 = packed
+        wgw = gate.wg.weight
+        S, M = x.shape
+        E, I = wgw.shape[0], w2.shape[2]
+        # the same validation the general path does per call, once
+        ops._check_ffn_weights(act, x, w1, b1, w2, b2)
+        ops._need(wgw, "wg.weight", wgw.dtype, 2)
+        if wgw.shape[1] != M or wgw.device != x.device or w1.shape[0] != E:
+            raise ValueError("wg.weight / expert weights do not match x")
+        cf = gate.capacity_factor if gate.training else gate.eval_capacity_factor
+        cap = capacity_of(S, E, cf * 2, gate.min_capacity)
+        max_rows = min(2 * S, E * cap) if gate.drop_tokens else 2 * S
+        lib = _lib.load()
+        ws_bytes = lib.moe_routing_workspace_bytes(S, E)
+        r = ops.Routing.allocate(S, E, 2, max_rows, cap, ws_bytes, x.device)
+        rows = max(max_rows, 1)
+        self.logits = torch.empty((S, E), dtype=torch.float32, device=x.device)
+        self.hy = torch.empty((rows * (I + M),), dtype=x.dtype, device=x.device)
+        a = _lib.BlockTop2Args()
+        a.wg, a.wg_dtype, a.logits = wgw.data_ptr(), ops._wg_dt(wgw, x), self.logits.data_ptr()
+        a.noise, a.noise_seed, a.noise_seed_dev = None, 0, None
+        a.S, a.M, a.E, a.I, a.act, a.capacity = S, M, E, I, act, cap
+        a.drop_tokens, a.n_gated = int(bool(gate.drop_tokens)), experts.n_gated
+        for name in ("expert_idx", "slot", "weight", "exp_counts", "kept_counts", "expert_offsets", "perm", "l_aux"):
+            setattr(a, name, r.ptr(name))
+        a.routing_ws, a.routing_ws_bytes = r.ptr("workspace"), ws_bytes
+        a.w1, a.b1 = w1.data_ptr(), (b1.data_ptr() if b1 is not None else None)
+        a.w2, a.b2 = w2.data_ptr(), (b2.data_ptr() if b2 is not None else None)
+        hp = self.hy.data_ptr()
+        a.h_ws, a.y = hp, hp + rows * I * 2
+        a.splitk_ws, a.splitk_ws_bytes = None, 0         # decode-size launches take the GEMV-style kernel: nothing to split
+        a.dtype, a.stream = ops._dt(x), st
+        self.args, self.ref = a, ctypes.byref(a)
+        self.routing, self.packed, self.S, self.M, self.cap = r, packed, S, M, cap
+        self.sampling = bool(gate.top2_2nd_expert_sampling)
+        self.fn = lib.moe_block_top2_fwd_args
+        self.l_aux, self.exp_counts = r.l_aux, r.exp_counts      # views, created once
+        self.dtype, self.dev = x.dtype, x.device
+        r._keep = (self.hy, wgw)
+
+    def run(self, gate: "TopKGate", x: Tensor) -> Tensor:
+        a = self.args
+        seed_dev = gate.__dict__.get("noise_seed_dev")            # graph.GraphedMoE: the seed lives on the device
+        noise = gate.noise_override
+        if not self.sampling:
+            a.noise, a.noise_seed, a.noise_seed_dev = None, 0, None
+        elif noise is not None:
+            if noise.dtype != torch.float32 or tuple(noise.shape) != (self.S, a.E) or noise.device != self.dev \
+                    or not noise.is_contiguous():
+                raise ValueError("noise_override must be a contiguous fp32 [S, E] tensor on x's device")
+            a.noise, a.noise_seed, a.noise_seed_dev = noise.data_ptr(), 0, None
+        elif seed_dev is not None:
+            a.noise, a.noise_seed, a.noise_seed_dev = None, 0, seed_dev.data_ptr()
+        else:
+            a.noise, a.noise_seed, a.noise_seed_dev = None, _fresh_seed(), None
+        out = torch.empty((self.S, self.M), dtype=self.dtype, device=self.dev)
+        a.x, a.out = x.data_ptr(), out.data_ptr()
+        rc = self.fn(self.ref)
+        if rc:
+            from . import _lib
+            _lib.check(rc, "moe_block_top2_fwd_args")
+        return out
+
+
 def _fresh_seed() -> int:
     return int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())
 
@@ -254,6 +339,10 @@ class MOELayer(nn.Module):
         if (local and not save and t is None and used_token is None and gate.k == 2 and not gate.wg._forward_hooks
                 and not (gate.noisy_gate_policy == "Jitter" and gate.training)):
             # inference on one GPU: the whole block in ONE library call (a decode step is host-bound otherwise)
+            if S <= DECODE_MAX_TOKENS and x.is_cuda:
+                res = self._decode_step(x_in, x, S)
+                if res is not None:
+                    return res
             experts = self.experts
             act, w1, b1, w2, b2 = experts.packed(x.device)
             wgw = gate.wg.weight
@@ -297,6 +386,34 @@ class MOELayer(nn.Module):
             saved.update(x=x, y=y, r=r, logits=self.gate.last_logits, jseed=self.gate.last_jitter_seed, act=act, w1=w1,
                          w2=w2, ng=ng, has_b1=b1 is not None, has_b2=b2 is not None)
         return out.reshape(x_in.shape), r.l_aux, saved
+
+    def _decode_step(self, x_in: Tensor, x: Tensor, S: int):
+        """Decode-size forward through a cached ``_DecodePlan`` (see there for what is reused between calls)."""
+        gate, experts = self.gate, self.experts
+        d = self.__dict__
+        st = ops._stream_ptr(x)
+        packed = experts.packed_unchanged()
+        if packed is None:
+            packed = experts.packed(x.device)
+            experts._remember_fast(experts._specs(), packed)
+            d["_decode_plans"] = {}
+            if experts.__dict__.get("_fast") is None:
+                return None                  # RePaMLP masks / externally owned parameters: the general path
+        plans = d.get("_decode_plans")
+        if plans is None:
+            plans = d["_decode_plans"] = {}
+        wgw = gate.wg.weight
+        key = (S, x.dtype, x.device.index, st, gate.training, wgw.data_ptr(), wgw.dtype, gate.capacity_factor,
+               gate.eval_capacity_factor, gate.min_capacity, gate.drop_tokens, gate.top2_2nd_expert_sampling)
+        plan = plans.get(key)
+        if plan is None or plan.packed is not packed:
+            if len(plans) >= 32:
+                plans.clear()
+            plan = plans[key] = _DecodePlan(self, x, packed, st)
+        out = plan.run(gate, x)
+        gate.__dict__["last_logits"] = plan.logits
+        d["exp_counts"], d["last_routing"] = plan.exp_counts, plan.routing
+        return out.reshape(x_in.shape), plan.l_aux, None
 
     def _backward(self, saved, dout: Tensor, dl_aux: Optional[Tensor]):
         """Gradients of the block: (dx, dwg fp32, dw1, db1, dw2, db2)."""

@@ -38,8 +38,17 @@ CASES = [
 
 @pytest.mark.parametrize("epi,K,N,rows,tile", CASES)
 def test_split_tail_matches_whole_tiles_and_reference(epi, K, N, rows, tile):
-    with knob("MOE_GEMM_TILE", tile):
+    # MOE_SPLITK_MIN=4: pieces of 4 K slices are allowed, so that the short-K shapes are split too (the default, 24, keeps
+    # the tail for launches whose tiles are long enough for it to pay)
+    with knob("MOE_GEMM_TILE", tile), knob("MOE_SPLITK_MIN", "4"):
         _check(epi, K, N, rows)
+
+
+def test_default_rule_splits_long_k_only():
+    """K = 10240 (config 3's fc2) is split by default, K = 2048 is not."""
+    _check(0, 10240, 2560, [3000, 2500, 1, 1356])
+    with pytest.raises(AssertionError, match="meant to be split"):
+        _check(1, 2048, 5632, [426, 437, 266, 279])
 
 
 def _check(epi, K, N, rows):
