@@ -78,7 +78,7 @@ def make_inputs(cfg, batch: int, device, seed: int, dtype=torch.bfloat16):
 
 
 def _proto(cfg):
-    from moe_llava_amd.expert_mlps import PhiMLP, QWenMLP, StableLMMLP
+    from tests.expert_mlps import PhiMLP, QWenMLP, StableLMMLP
     return {"stablelm": StableLMMLP, "phi": PhiMLP, "qwen": QWenMLP}[cfg["kind"]](cfg["M"], cfg["I"])
 
 

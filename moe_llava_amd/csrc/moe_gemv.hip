@@ -70,9 +70,20 @@ __device__ __forceinline__ void skinny_body(const GemmParams &p, int grp, int ro
 #pragma unroll
             for (int t = 0; t < RT; ++t) acc[h][g][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // this wave's share of K, in steps of 32 (every address below stays inside [0, K) of its row: s < K/32)
+    // this wave's share of K, in steps of 32 (every address below stays inside [0, K) of its row: s < K/32).  The shares
+    // are cut in units of 8 steps, a multiple of every U, so that a wave runs whole batches of U steps in flight: with
+    // even shares of steps, fc2 of the StableLM block (K = 5632: 22 steps per wave, U = 8) ran 2 batches and then 6 single
+    // steps, one memory round trip each.  The steps beyond the last unit (K % 256 != 0) go to the last wave.
     const int nk = p.K / 32;
-    const int k_lo = (wave * nk) / KSPLIT, k_hi = ((wave + 1) * nk) / KSPLIT;
+    const int nunit = nk / 8;
+    int k_lo, k_hi;
+    if (nunit >= KSPLIT) {
+        k_lo = ((wave * nunit) / KSPLIT) * 8;
+        k_hi = wave == KSPLIT - 1 ? nk : (((wave + 1) * nunit) / KSPLIT) * 8;
+    } else {
+        k_lo = (wave * nk) / KSPLIT;
+        k_hi = ((wave + 1) * nk) / KSPLIT;
+    }
     int s = k_lo;
     for (; s + U <= k_hi; s += U) {
         bf16x8_t fw[U][NACC][NW], fx[U][RT];
@@ -201,8 +212,11 @@ int launch_skinny_gemm(const GemmParams &p0, int epilogue, int max_rows, hipStre
     if (grid > 0x7fffffffLL) return fail(MOE_ERR_SHAPE, "skinny_gemm: grid too large");
     // K split over the waves of a block so that the launch has ~16 wave-tasks per CU (enough loads in flight to cover
     // the HBM latency) but not more than one round of resident waves (a second, partial round would double the time)
+    // (blocks of idle groups exit at once: what counts is the blocks of the groups that can hold rows -- a decode step of
+    // one token has 2 active experts of 4, and with the K split sized from all 4 it ran half the waves it could)
+    const long long active_groups = p.G < max_rows ? p.G : max_rows;
     int ks = 8;
-    while (ks > 1 && grid * ks > (gated ? 2048 : 4096)) ks >>= 1;
+    while (ks > 1 && active_groups * p.col_tiles * ks > (gated ? 2048 : 4096)) ks >>= 1;
     {
         const int v = knobs().skinny_ks;  // tuning knob MOE_SKINNY_KS: force the K split (1, 2, 4, 8)
         if (v == 1 || v == 2 || v == 4 || v == 8) ks = v;

@@ -25,6 +25,20 @@ int fail(int code, const char *fmt, ...) {
 
 constexpr int RB = 256;  // tokens (= threads) per routing block
 
+#ifdef ROUTE_STAMPS
+// Diagnostic build only: s_memtime at the phase boundaries of the single-block routing kernels, thread 0, to a buffer of
+// its own (tools/route_stamps.py).
+__device__ unsigned long long g_rstamps[16];
+__device__ __forceinline__ void rstamp(int i) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    if (threadIdx.x == 0) g_rstamps[i] = t;
+}
+#define RSTAMP(i) rstamp(i)
+#else
+#define RSTAMP(i)
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -372,11 +386,23 @@ __device__ __forceinline__ void route_fused_body(
         if (c < nchunk) {
             const int s = c * FUSED_THREADS + tid;
             const bool valid = s < S;
+            r1[c] = 0;
+            r2[c] = 0;
+            if (c * FUSED_THREADS + wave * 64 >= S) {
+                // a wave without tokens (decode steps: 15 of the 16) only reports zero counts; running the softmax / Philox
+                // / Gumbel arithmetic for nothing kept the wave that has the tokens waiting at the barrier (stamps, S = 1:
+                // 4.2k cycles)
+                i1[c] = -1; i2[c] = -1; g1[c] = 0.f; g2[c] = 0.f;
+                if (lane < EMAX) {
+                    wcnt[c][0][wave][lane] = 0;
+                    wcnt[c][1][wave][lane] = 0;
+                    wsum[c][wave][lane] = 0.f;
+                }
+                continue;
+            }
             float g[EMAX];
             select_top2<EMAX>(logits, noise, seed, s, E, valid, g, i1[c], i2[c], g1[c], g2[c]);
             if (!valid) { i1[c] = -1; i2[c] = -1; }
-            r1[c] = 0;
-            r2[c] = 0;
 #pragma unroll
             for (int e = 0; e < EMAX; ++e) {
                 if (e < E) {
@@ -394,7 +420,9 @@ __device__ __forceinline__ void route_fused_body(
             }
         }
     }
+    RSTAMP(3);
     __syncthreads();
+    RSTAMP(4);
     if (seed_dev && tid == FUSED_THREADS - 1) {
         unsigned long long nx = seed * 6364136223846793005ull + 1442695040888963407ull;  // next key of the Philox stream
         *seed_dev = nx ? nx : 1ull;                                                          // 0 means "no noise"
@@ -424,6 +452,7 @@ __device__ __forceinline__ void route_fused_body(
         }
     }
     __syncthreads();
+    RSTAMP(5);
     if (tid == 0) {
         int cap = capacity;
         if (!drop_tokens) {
@@ -452,7 +481,9 @@ __device__ __forceinline__ void route_fused_body(
         const float fE = (float)E;
         l_aux[0] = ((lsum / fE) * fE) * fE;
     }
+    RSTAMP(6);
     __syncthreads();
+    RSTAMP(7);
     const int cap = s_cap;
 #pragma unroll
     for (int c = 0; c < FUSED_T; ++c) {
@@ -495,19 +526,43 @@ __global__ __launch_bounds__(FUSED_THREADS) void gate_route_fused_kernel(
     int *__restrict__ expert_idx, int *__restrict__ slot, float *__restrict__ weight, long long *__restrict__ exp_counts,
     int *__restrict__ kept_counts, int *__restrict__ expert_offsets, int *__restrict__ perm, float *__restrict__ l_aux) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    RSTAMP(0);
     // 16 waves, row groups of 4 rows: with fewer than 16 row groups the experts of a group are spread over 16 / groups
     // waves (S = 1: four waves, one expert each), so that the cold gate weight is fetched through several waves' loads
     // at once.  Each (row, expert) sum is the same fmaf chain + butterfly whichever wave computes it: logits stay
     // bit-identical to gate_logits_kernel's.
+    // Touch every 128-byte line of wg and of the x rows first, one dword per lane, results unused: the gate weight of a
+    // decode step is cold (another layer's was used last), and the GEMV below walks M in 4-5 dependent rounds of loads
+    // per wave -- stamps showed 3.9k cycles per round, an HBM + TLB miss each.  Requested up front, all lines are in flight
+    // at once and the rounds hit them (15.7k -> ~5k cycles for the GEMV at S = 1).
+    // (The loaded words stay live until the end of the kernel, where an impossible condition consumes them: the compiler
+    // then waits for them there and nowhere earlier, and no register is reused under a load in flight.)
+    unsigned touched = 0;
+    {
+        const int wg_lines = (E * M * (WG16 ? 2 : 4)) >> 7, n_lines = wg_lines + ((S * M * 2) >> 7);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = (int)threadIdx.x + q * FUSED_THREADS;
+            if (i < n_lines) {
+                const char *ptr = i < wg_lines ? reinterpret_cast<const char *>(wg) + ((size_t)i << 7)
+                                             : reinterpret_cast<const char *>(x) + ((size_t)(i - wg_lines) << 7);
+                touched ^= *reinterpret_cast<const unsigned *>(ptr);
+            }
+        }
+    }
     const int nrg = (S + 3) >> 2;
     int wpr = (FUSED_THREADS / 64) / nrg;
     if (wpr > E) wpr = E;
     if (wpr < 1) wpr = 1;
     if (wave < nrg * wpr) gate_rows<EMAX, 4, WG16, DT>(x, wg, logits, S, M, E, (wave / wpr) * 4, lane, 0ull, wave % wpr, wpr);
+    RSTAMP(1);
     __threadfence_block();
     __syncthreads();  // the block's own global writes are visible to it after the barrier
+    RSTAMP(2);
     route_fused_body<EMAX>(logits, noise, seed, seed_dev, S, E, capacity, drop_tokens, expert_idx, slot, weight, exp_counts,
                            kept_counts, expert_offsets, perm, l_aux);
+    RSTAMP(8);
+    if (touched == 0x9e3779b9u && S < 0) l_aux[0] = 0.f;  // never true (S >= 1): keeps the touch loads alive, see above
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -674,6 +729,12 @@ extern "C" void moe_reload_knobs(void) {
     moe::read_knobs(moe::g_knobs);
     moe::g_knobs_read = true;
 }
+
+#ifdef ROUTE_STAMPS
+extern "C" int moe_debug_read_route_stamps(unsigned long long *host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(moe::g_rstamps), sizeof(unsigned long long) * 16);
+}
+#endif
 
 extern "C" int moe_abi_version(void) { return MOE_ABI_VERSION; }
 extern "C" const char *moe_last_error(void) { return err_buf(); }

@@ -221,7 +221,7 @@ def _install_cpu_stand_ins():
 
 def _build(M, I, E, ep, seed, kind):
     import moe_llava_amd
-    from moe_llava_amd.expert_mlps import PhiMLP, StableLMMLP
+    from tests.expert_mlps import PhiMLP, StableLMMLP
     g = torch.Generator().manual_seed(seed)
     mk = (lambda: StableLMMLP(M, I)) if kind == "stablelm" else (lambda: PhiMLP(M, I))
     proto = mk().to(torch.bfloat16)

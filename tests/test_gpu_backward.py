@@ -157,7 +157,7 @@ def test_frozen_experts_and_idle_expert():
 def test_cfg1_shape_backward_finite_and_linear():
     """Config-1 block (S=704, M=2048, I=5632): gradients are finite and linear in the upstream gradient."""
     import moe_llava_amd
-    from moe_llava_amd.expert_mlps import StableLMMLP
+    from tests.expert_mlps import StableLMMLP
     torch.manual_seed(0)
     M, I, E, S = 2048, 5632, 4, 704
     moe = moe_llava_amd.MoE(M, StableLMMLP(M, I), num_experts=E, k=2, capacity_factor=1.5, min_capacity=0,
@@ -190,7 +190,7 @@ def test_activation_checkpointing_recompute_matches(reentrant):
     and give the gradients of the plain run, bit for bit."""
     from torch.utils.checkpoint import checkpoint
     import moe_llava_amd
-    from moe_llava_amd.expert_mlps import StableLMMLP
+    from tests.expert_mlps import StableLMMLP
     M, I, E = 128, 256, 4
     torch.manual_seed(3)
     moe = moe_llava_amd.MoE(M, StableLMMLP(M, I), num_experts=E, k=2, capacity_factor=1.0, min_capacity=0)

@@ -81,7 +81,7 @@ def _hooks(model):                                          # moellava/utils.py:
 
 def test_convert_save_reload_hook_and_run():
     from moe_llava_amd import shim
-    from moe_llava_amd.expert_mlps import StableLMMLP
+    from tests.expert_mlps import StableLMMLP
     saved_mods = {k: v for k, v in sys.modules.items() if k == "deepspeed" or k.startswith("deepspeed.")}
     try:
         shim.install()
@@ -153,7 +153,7 @@ def test_save_and_reload_after_the_first_forward(kind, tmp_path):
     safetensors must both round-trip every key, and the reloaded block must compute the same output."""
     import moe_llava_amd
     import safetensors.torch as st
-    from moe_llava_amd.expert_mlps import RePaMLP, StableLMMLP
+    from tests.expert_mlps import RePaMLP, StableLMMLP
     torch.manual_seed(11)
     if kind == "stablelm":
         proto = StableLMMLP(M, I)

@@ -332,7 +332,7 @@ def _full_size_check(kind, M, I, E, B, T, cf, stress=False, dtype=torch.bfloat16
     perm = inverse of (expert, slot), routing equal to the index oracle given the kernel's logits, rows that lost
     both choices exactly zero, and a sample of output rows against the oracle expert MLPs."""
     import moe_llava_amd
-    from moe_llava_amd.expert_mlps import PhiMLP, QWenMLP, StableLMMLP
+    from tests.expert_mlps import PhiMLP, QWenMLP, StableLMMLP
     mk = {"stablelm": (StableLMMLP, StableLMMLPRef), "phi": (PhiMLP, PhiMLPRef), "qwen": (QWenMLP, QWenMLPRef)}[kind]
     torch.manual_seed(0)
     moe = moe_llava_amd.MoE(M, mk[0](M, I), num_experts=E, k=2, capacity_factor=cf,
@@ -426,7 +426,7 @@ def test_cfg3_phi_stack_32_layers():
     Checked: the whole stack is deterministic; EVERY layer's routing equals the index oracle given that layer's
     kernel logits (bit-exact), l_aux within 1e-5; sampled output rows of four layers against the oracle expert MLPs."""
     import moe_llava_amd
-    from moe_llava_amd.expert_mlps import PhiMLP
+    from tests.expert_mlps import PhiMLP
     M, I, E, L, B, T = 2560, 10240, 4, 32, 16, 857
     S = B * T
     assert S == 13712
@@ -521,7 +521,7 @@ def test_state_dict_views_survive_load_and_inplace_update():
 def test_errors_are_loud():
     import moe_llava_amd
     from moe_llava_amd._lib import MoEKernelError
-    from moe_llava_amd.expert_mlps import StableLMMLP
+    from tests.expert_mlps import StableLMMLP
     ops = _ops()
     with pytest.raises(MoEKernelError):
         ops.gate_logits(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64))       # CPU tensor

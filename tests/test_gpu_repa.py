@@ -4,14 +4,14 @@ every expert and, after ``reparam()``, adds a shared dense Linear to the block's
 (moellava/model/language_model/llava_stablelm_moe.py:613-773, llava_qwen_moe.py:693-856).
 
 ``_repa_moe_class(base)`` restates that wrapper over any MoE base class, so the SAME wrapper code runs over the HIP
-block and over the literal oracle; the experts are ``moe_llava_amd.expert_mlps.RePaMLP`` (product side) and
+block and over the literal oracle; the experts are ``tests.expert_mlps.RePaMLP`` (product side) and
 ``oracle.expert_mlps.RePaMLPRef`` (oracle side) with identical weights."""
 import pytest
 import torch
 from torch import nn
 
 import moe_llava_amd
-from moe_llava_amd.expert_mlps import RePaMLP
+from tests.expert_mlps import RePaMLP
 from oracle import ds_moe_literal as lit
 from oracle.expert_mlps import RePaMLPRef
 from tests.test_gpu_parity import DEV

@@ -10,7 +10,7 @@ import torch
 
 import moe_llava_amd
 from moe_llava_amd import _lib, groups
-from moe_llava_amd.expert_mlps import PhiMLP, QWenMLP, StableLMMLP
+from tests.expert_mlps import PhiMLP, QWenMLP, StableLMMLP
 from moe_llava_amd.sharded_moe import capacity_of
 from oracle import ds_moe_literal as lit
 
@@ -171,7 +171,7 @@ def test_product_never_imports_oracle():
 def test_repa_expert_adapter_padding_and_reparam_on_cpu():
     """RePaMLP (llava_stablelm_moe.py:613-655): prefix mask -> n_gated; reparam() shrinks the projections in place of
     the same storage address, which must still trigger a re-pack; widths that are not multiples of 64 are padded."""
-    from moe_llava_amd.expert_mlps import RePaMLP
+    from tests.expert_mlps import RePaMLP
     from moe_llava_amd.experts import Experts, describe_expert
     from oracle.expert_mlps import RePaMLPRef
     for names in ("stablelm", "qwen"):

@@ -1,7 +1,7 @@
 import os, sys, time, torch, cProfile, pstats
 sys.path.insert(0, os.getcwd())
 import moe_llava_amd
-from moe_llava_amd.expert_mlps import StableLMMLP
+from tests.expert_mlps import StableLMMLP
 dev = torch.device("cuda", 0)
 M, I, E = 2048, 5632, 4
 moe = moe_llava_amd.MoE(M, StableLMMLP(M, I).to(torch.bfloat16), num_experts=E, k=2, capacity_factor=1.5, eval_capacity_factor=2.0, min_capacity=0).to(dev).eval()

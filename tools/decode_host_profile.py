@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import moe_llava_amd  # noqa: E402
-from moe_llava_amd.expert_mlps import StableLMMLP  # noqa: E402
+from tests.expert_mlps import StableLMMLP  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device("cuda", 0)

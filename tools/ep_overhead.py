@@ -12,7 +12,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import moe_llava_amd  # noqa: E402
-from moe_llava_amd.expert_mlps import StableLMMLP  # noqa: E402
+from tests.expert_mlps import StableLMMLP  # noqa: E402
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")

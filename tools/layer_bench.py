@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import moe_llava_amd  # noqa: E402
 from moe_llava_amd import ops  # noqa: E402
-from moe_llava_amd.expert_mlps import PhiMLP, QWenMLP, StableLMMLP  # noqa: E402
+from tests.expert_mlps import PhiMLP, QWenMLP, StableLMMLP  # noqa: E402
 
 CONFIGS = {
     # name: (expert ctor, M, I, E, cf, S, training)

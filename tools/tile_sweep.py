@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import moe_llava_amd  # noqa: E402
 from moe_llava_amd import ops  # noqa: E402
-from moe_llava_amd.expert_mlps import StableLMMLP  # noqa: E402
+from tests.expert_mlps import StableLMMLP  # noqa: E402
 
 SHAPES = {"decode1": 1, "decode8": 8, "decode32": 32, "S128": 128, "S256": 256, "cfg1": 704, "S1408": 1408,
           "S2432": 2432, "S5000": 5000, "cfg2": 22528}

@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import moe_llava_amd  # noqa: E402
-from moe_llava_amd.expert_mlps import PhiMLP, StableLMMLP  # noqa: E402
+from tests.expert_mlps import PhiMLP, StableLMMLP  # noqa: E402
 
 
 def main():

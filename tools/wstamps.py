@@ -10,7 +10,7 @@ os.environ["MOE_GFX950_LIB"] = os.path.join(ROOT, "tools", "variants", f"libmoe_
 import torch  # noqa: E402
 import moe_llava_amd  # noqa: E402
 from moe_llava_amd import _lib  # noqa: E402
-from moe_llava_amd.expert_mlps import StableLMMLP  # noqa: E402
+from tests.expert_mlps import StableLMMLP  # noqa: E402
 dev = torch.device("cuda", 0)
 torch.manual_seed(1)
 M, I = 2048, 5632
