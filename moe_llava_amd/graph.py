@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 from torch import Tensor
 
-from . import ops
+from . import ops, sharded_moe
 
 
 class GraphedMoE:
@@ -37,7 +37,7 @@ class GraphedMoE:
         if layer.ep_size != 1 or layer.force_exchange:
             raise NotImplementedError("GraphedMoE: expert-parallel steps are not captured (the exchange sizes its "
                                       "splits on the host)")
-        if gate.k != 2 or gate.noisy_gate_policy is not None or gate.wg._forward_hooks or layer.timer is not None:
+        if gate.k != 2 or gate.noisy_gate_policy is not None or sharded_moe.module_has_hooks(gate.wg) or layer.timer is not None:
             raise NotImplementedError("GraphedMoE: needs the one-call path (top-2 gate, no noisy_gate_policy, no "
                                       "forward hooks on wg, no phase timer)")
         S = example.numel() // example.shape[-1]

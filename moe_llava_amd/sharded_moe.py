@@ -69,15 +69,28 @@ class TopKGate(nn.Module):
         self.ep_group = ep_group
 
     def logits(self, x: Tensor, jitter_seed: int = 0) -> Tensor:
-        lg = ops.gate_logits(x, self.wg.weight.detach(), jitter_seed)
+        wg = self.wg
+        if not module_has_hooks(wg):
+            return ops.gate_logits(x, wg.weight.detach(), jitter_seed)
         # upstream 0.9.5 calls self.wg(input) so forward hooks fire; 0.17.5 uses F.linear and they do not.
-        # The reference's gating-logit capture (moellava/utils.py:38-46) relies on them: fire them by hand.
-        if self.wg._forward_hooks:
-            for hook in list(self.wg._forward_hooks.values()):
-                res = hook(self.wg, (x,), lg)
-                if res is not None:
-                    lg = res
-        return lg
+        # The reference's gating-logit capture (moellava/utils.py:38-46) relies on them.  With any hook registered the
+        # kernel runs as the module's forward INSIDE nn.Module.__call__, so every kind of hook keeps torch's own
+        # semantics (forward hooks with or without kwargs, pre-hooks that may replace the input, always-called and
+        # global hooks); the hooks see the fp32 [S, E] logits as output.
+        def kernel_forward(inp, *args, **kwargs):
+            if args or kwargs:
+                raise TypeError("wg takes one positional input (a hook handed it more)")
+            return ops.gate_logits(inp, wg.weight.detach(), jitter_seed)
+        wg.__dict__["forward"] = kernel_forward          # instance attribute: shadows nn.Linear.forward for this call
+        try:
+            lg = wg(x)
+        finally:
+            wg.__dict__.pop("forward", None)
+        if not isinstance(lg, Tensor) or lg.dtype != torch.float32 or lg.shape != (x.shape[0], wg.weight.shape[0]) \
+                or lg.device != x.device:
+            raise TypeError("a forward hook on wg replaced the logits by something that is not an fp32 [S, E] tensor on "
+                            "the activations' device")
+        return lg.contiguous()
 
     def forward(self, x: Tensor, used_token: Optional[Tensor] = None) -> ops.Routing:
         """Returns the index-form routing (upstream returns dense combine/dispatch masks; nothing in the
@@ -221,6 +234,12 @@ class _DecodePlan:
         return out
 
 
+def module_has_hooks(m: nn.Module) -> bool:
+    """Any forward / forward-pre hook that nn.Module.__call__ would run for ``m`` (its own or torch's global ones)."""
+    import torch.nn.modules.module as tm
+    return bool(m._forward_hooks or m._forward_pre_hooks or tm._global_forward_hooks or tm._global_forward_pre_hooks)
+
+
 def _fresh_seed() -> int:
     return int(torch.randint(1, 2 ** 62, (1,), dtype=torch.int64).item())
 
@@ -336,7 +355,7 @@ class MOELayer(nn.Module):
         if gate.k == 2:
             used_token = None              # ignored by upstream top2gating
         local = self.ep_size == 1 and not (self.force_exchange and self.ep_group is not None)
-        if (local and not save and t is None and used_token is None and gate.k == 2 and not gate.wg._forward_hooks
+        if (local and not save and t is None and used_token is None and gate.k == 2 and not module_has_hooks(gate.wg)
                 and not (gate.noisy_gate_policy == "Jitter" and gate.training)):
             # inference on one GPU: the whole block in ONE library call (a decode step is host-bound otherwise)
             if S <= DECODE_MAX_TOKENS and x.is_cuda:

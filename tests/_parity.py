@@ -61,3 +61,34 @@ class knob:
             os.environ[self.name] = self.prev
         ops.reload_knobs()
         return False
+
+
+def edge_tokens(expert_offsets, perm, top_k, bm, n_random=0, seed=0, per_expert=8):
+    """Tokens whose compact rows sit where a tiling bug would show: the first and last row of every expert, the rows on
+    either side of row-tile boundaries (tiles of ``bm`` rows start at the expert's first row: the first two and last two
+    boundaries plus ``per_expert`` random ones), and the first / middle / last row of the expert's last partial tile.
+    ``perm[p] = token * top_k + choice`` (the kernels' dispatch index); returns a sorted LongTensor of distinct tokens,
+    plus ``n_random`` random compact rows' tokens."""
+    import torch
+    offs = [int(v) for v in expert_offsets]
+    g = torch.Generator().manual_seed(seed)
+    rows = set()
+    for e in range(len(offs) - 1):
+        lo, hi = offs[e], offs[e + 1]
+        if hi <= lo:
+            continue
+        rows |= {lo, hi - 1}
+        nb = (hi - lo - 1) // bm                           # boundaries strictly inside the expert's rows
+        bs = list(range(1, nb + 1))
+        pick = set(bs[:2] + bs[-2:])
+        if len(bs) > 4:
+            pick |= {bs[int(i)] for i in torch.randint(0, len(bs), (per_expert,), generator=g)}
+        for t in pick:
+            rows |= {lo + t * bm - 1, lo + t * bm}
+        last = lo + nb * bm                                # the last (possibly partial) tile
+        rows |= {last, (last + hi - 1) // 2, hi - 1}
+    n = offs[-1]
+    if n_random and n > 0:
+        rows |= {int(i) for i in torch.randint(0, n, (n_random,), generator=g)}
+    idx = torch.tensor(sorted(rows), dtype=torch.long)
+    return torch.unique(perm.cpu().long()[idx] // top_k)

@@ -182,6 +182,94 @@ def test_cfg1_shape_backward_finite_and_linear():
         assert torch.equal(2.0 * a, b)
 
 
+def test_cfg2_full_size_backward_slices_vs_fp32_reference():
+    """BASELINE config 2 at its real size (S = 22 528, M = 2048, I = 5632, 4 experts, cf 1.5): one training step of the HIP
+    block, then on the CPU, from the step's inputs alone (x, weights, the kernel's routing, the upstream gradient R):
+      * for every expert, 48 columns of the hidden width (both sides of a 256-column tile edge and the last columns):
+        the down_proj weight-gradient columns dW2[:, c] = dY_e^T h[:, c], and the gate_proj / up_proj weight-gradient rows
+        dW1[c, :] = dAB[:, c]^T X_e, with dY, h, dH, dAB rebuilt in fp32 torch with the bf16 rounding points of autograd
+        over the reference's bf16 modules;
+      * dx of ~100 tokens (random ones and the ones whose compact rows sit at expert ends and 256-row tile edges) by
+        torch autograd over the oracle expert modules for those tokens, the gate included.
+    The small-shape tests compare every gradient element; this one is the check that nothing breaks at real K, real row
+    counts (176 row tiles, ragged expert ends) and real tile counts."""
+    import moe_llava_amd
+    from oracle.expert_mlps import StableLMMLPRef
+    from tests._parity import edge_tokens
+    from tests.expert_mlps import StableLMMLP
+    torch.manual_seed(5)
+    M, I, E, B, T = 2048, 5632, 4, 32, 704
+    S = B * T
+    moe = moe_llava_amd.MoE(M, StableLMMLP(M, I), num_experts=E, k=2, capacity_factor=1.5, min_capacity=0,
+                            top2_2nd_expert_sampling=False).to(torch.bfloat16)
+    for p in moe.deepspeed_moe.experts.parameters():
+        p.data.normal_(0, 0.02)
+    moe.deepspeed_moe.gate.wg.weight.data = torch.randn(E, M) * 0.05
+    moe = moe.to(DEV).train()
+    x = torch.randn(B, T, M, device=DEV)
+    x[:, :576] += 0.5                                          # image rows skew the router: drops happen
+    x = x.to(torch.bfloat16)
+    R = torch.randn(B, T, M, device=DEV).to(torch.bfloat16)
+    aux_c = 0.01
+    xg = x.clone().requires_grad_(True)
+    out, l_aux, _ = moe(xg)
+    torch.autograd.backward([out, l_aux], [R, torch.tensor(aux_c, device=DEV)])
+    torch.cuda.synchronize()
+    r = moe.deepspeed_moe.last_routing
+    offs = r.expert_offsets.cpu().tolist()
+    perm = r.perm.cpu().long()
+    idx, slot, wt = r.expert_idx.cpu().long(), r.slot.cpu().long(), r.weight.cpu()
+    assert int((slot < 0).sum()) > 0 and offs[-1] > 40000
+    xc, Rc = x.reshape(S, M).cpu(), R.reshape(S, M).cpu()
+    rb = lambda t: t.to(torch.bfloat16).float()                # a bf16 rounding point
+    cols = torch.tensor(list(range(0, 16)) + list(range(248, 264)) + list(range(I - 16, I)))
+    experts = list(moe.deepspeed_moe.experts.deepspeed_experts)
+    for e in range(E):
+        rows = perm[offs[e]:offs[e + 1]]
+        tok, ch = rows // 2, rows % 2
+        Xe = xc[tok].float()
+        wq = rb(wt[tok, ch])                                   # combine weights are rounded to bf16 first
+        dY = rb(wq[:, None] * Rc[tok].float())                 # combine backward: dY[p] = bf16(w) * dOut[token]
+        mod = experts[e]
+        Wg, Wu, Wd = (mod.gate_proj.weight.detach().cpu().float(), mod.up_proj.weight.detach().cpu().float(),
+                      mod.down_proj.weight.detach().cpu().float())
+        a, b = rb(Xe @ Wg[cols].T), rb(Xe @ Wu[cols].T)
+        sig = torch.sigmoid(a)
+        sg = rb(a * sig)
+        h = rb(sg * b)
+        _cmp(f"cfg2 expert {e} down_proj.weight.grad[:, cols]", mod.down_proj.weight.grad[:, cols.to(DEV)], dY.T @ h)
+        dH = rb(dY @ Wd[:, cols])
+        dsg, db = rb(dH * b), rb(dH * sg)
+        da = rb(dsg * (sig * (1 + a * (1 - sig))))
+        _cmp(f"cfg2 expert {e} gate_proj.weight.grad[cols]", mod.gate_proj.weight.grad[cols.to(DEV)], da.T @ Xe)
+        _cmp(f"cfg2 expert {e} up_proj.weight.grad[cols]", mod.up_proj.weight.grad[cols.to(DEV)], db.T @ Xe)
+    # ---- dx of sampled tokens: autograd over the oracle modules, routing decisions taken from the kernel ----
+    smp = torch.unique(torch.cat([torch.randperm(S, generator=torch.Generator().manual_seed(3))[:48],
+                                  edge_tokens(offs, r.perm, 2, 256, seed=4, per_expert=2)]))
+    cpu_experts = [StableLMMLPRef(M, I).to(torch.bfloat16) for _ in range(E)]
+    for ce_, ge in zip(cpu_experts, experts):
+        ce_.load_state_dict({k: v.detach().cpu() for k, v in ge.state_dict().items()})
+    wg = moe.deepspeed_moe.gate.wg.weight.detach().cpu().float()
+    n1 = torch.bincount(idx[:, 0], minlength=E).float()
+    xs = xc[smp].clone().requires_grad_(True)
+    gates = torch.softmax(xs.float() @ wg.T, dim=1)
+    keep = (slot[smp] >= 0).float()
+    g = gates.gather(1, idx[smp]) * keep
+    w = g / torch.clamp(g.sum(1, keepdim=True), min=torch.finfo(torch.float32).eps)
+    acc = torch.zeros(smp.numel(), M)
+    for e in range(E):
+        for j in range(2):
+            on = torch.nonzero((idx[smp, j] == e) & (slot[smp, j] >= 0))[:, 0]
+            if on.numel():
+                y = cpu_experts[e](xs[on])
+                acc = acc.index_add(0, on, w[on, j, None].to(torch.bfloat16).float() * y.float())
+    o = acc.to(torch.bfloat16)
+    loss = (o.float() * Rc[smp].float()).sum() + aux_c * (E / S) * (gates * (n1 / S)).sum()   # l_aux = E * sum_e me_e ce_e
+    loss.backward()
+    _cmp("cfg2 out (sampled tokens)", out.reshape(S, M)[smp.to(DEV)], o, tol=1e-2)
+    _cmp(f"cfg2 dx ({smp.numel()} sampled tokens)", xg.grad.reshape(S, M)[smp.to(DEV)], xs.grad)
+
+
 @pytest.mark.parametrize("reentrant", [True, False])
 def test_activation_checkpointing_recompute_matches(reentrant):
     """The reference fine-tunes with --gradient_checkpointing True (scripts/v1/stablelm/finetune_moe.sh:44): every decoder

@@ -10,7 +10,7 @@ import torch
 from oracle import ds_moe_index as ix
 from oracle import ds_moe_literal as lit
 from oracle.expert_mlps import PhiMLPRef, QWenMLPRef, StableLMMLPRef
-from tests._parity import assert_out_close, knob, report as _report
+from tests._parity import assert_out_close, edge_tokens, knob, report as _report
 
 pytestmark = pytest.mark.gpu
 
@@ -286,6 +286,48 @@ def test_gate_jitter_factors_and_logits(S, M, E):
     assert float((plain.double() - ref).abs().max()) > 10 * float((lg.double() - ref).abs().max())
 
 
+def test_wg_hooks_of_every_kind_fire_with_torch_semantics():
+    """The reference captures gating logits with plain forward hooks on every nn.Linear named wg (moellava/utils.py:38-46).
+    With any hook registered the gate kernel runs as wg's forward inside nn.Module.__call__: pre-hooks (which may replace
+    the input), hooks registered with_kwargs, and torch's global module hooks all fire, and all see the fp32 [S,E] logits."""
+    import torch.nn.modules.module as tm
+    ref, mine, x = _build_pair("stablelm", 64, 128, 4, (2, 50), 1.0, seed=4)
+    wg = mine.deepspeed_moe.gate.wg
+    S = 100
+    seen = {}
+    with torch.no_grad():
+        base, _, _ = mine(x.to(DEV))                            # no hooks: the one-call path
+        base_lg = mine.deepspeed_moe.gate.last_logits.clone()
+        hs = [wg.register_forward_pre_hook(lambda m, inp: seen.__setitem__("pre", tuple(inp[0].shape))),
+              wg.register_forward_hook(lambda m, a, kw, o: seen.__setitem__("kw", (kw, o.dtype, tuple(o.shape))), with_kwargs=True),
+              wg.register_forward_hook(lambda m, i, o: seen.__setitem__("plain", o.detach().cpu().clone())),
+              tm.register_module_forward_hook(lambda m, i, o: seen.__setitem__("global", True) if m is wg else None)]
+        try:
+            out, _, _ = mine(x.to(DEV))
+        finally:
+            for h in hs:
+                h.remove()
+        assert seen["pre"] == (S, 64) and seen["kw"] == ({}, torch.float32, (S, 4)) and seen["global"] is True
+        assert torch.equal(seen["plain"], base_lg.cpu()) and torch.equal(out, base)
+        # a pre-hook that replaces the input changes the logits the routing uses (as it would for an eager nn.Linear)
+        h = wg.register_forward_pre_hook(lambda m, inp: (inp[0] * 0,))
+        try:
+            mine(x.to(DEV))
+        finally:
+            h.remove()
+        assert float(mine.deepspeed_moe.gate.last_logits.abs().max()) == 0.0
+        # a hook that returns a replacement of the wrong kind is refused, not silently used
+        h = wg.register_forward_hook(lambda m, i, o: o.to(torch.bfloat16))
+        try:
+            with pytest.raises(TypeError):
+                mine(x.to(DEV))
+        finally:
+            h.remove()
+        assert "forward" not in wg.__dict__                     # the instance-level forward never leaks
+        again, _, _ = mine(x.to(DEV))
+        assert torch.equal(again, base)
+
+
 def test_eval_mode_uses_eval_capacity_and_s1_decode():
     ref, mine, x = _build_pair("stablelm", 64, 128, 4, (1, 1), 1.0, seed=3, training=False)
     with torch.no_grad():
@@ -319,7 +361,10 @@ def test_cfg1_block_vs_index_oracle(kind, M, I):
     r = ix.route_top2(lg, C)
     assert torch.equal(cnt.cpu(), r["exp_counts"])
     assert torch.equal(mine.deepspeed_moe.last_routing.slot.cpu(), r["slot"])
-    sample = torch.randperm(S, generator=torch.Generator().manual_seed(0))[:96]
+    rt = mine.deepspeed_moe.last_routing
+    # random tokens + the tokens at the experts' first / last rows and around the 128-row tile edges of this launch
+    sample = torch.unique(torch.cat([torch.randperm(S, generator=torch.Generator().manual_seed(0))[:64],
+                                     edge_tokens(rt.expert_offsets.cpu(), rt.perm, 2, 128, seed=1)]))
     sub = {k: (v[sample] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == S else v) for k, v in r.items()}
     with torch.no_grad():
         want = ix.moe_forward_index(x.reshape(-1, M)[sample], sub, list(ref.deepspeed_moe.experts.deepspeed_experts))
@@ -360,7 +405,8 @@ def _full_size_check(kind, M, I, E, B, T, cf, stress=False, dtype=torch.bfloat16
     assert int(kept.max()) <= C
     offs = r.expert_offsets.cpu()
     n = int(offs[-1])
-    perm = r.perm.cpu()[:n].long()
+    perm_raw = r.perm.cpu()
+    perm = perm_raw[:n].long()
     assert perm.unique().numel() == n                                   # each (token, choice) at most once
     slot, idx = r.slot.cpu().long(), r.expert_idx.cpu().long()
     tok, ch = perm // 2, perm % 2
@@ -378,8 +424,13 @@ def _full_size_check(kind, M, I, E, B, T, cf, stress=False, dtype=torch.bfloat16
         assert float(o[dead.to(DEV)].float().abs().max()) == 0.0
     if stress:
         assert int((slot < 0).sum()) > 0                                # the stress really drops
-    # sampled rows against the oracle MLPs
-    sample = torch.randperm(S, generator=torch.Generator().manual_seed(1))[:48]
+    # sampled rows against the oracle MLPs: random tokens, plus the tokens whose compact rows are the first / last row of
+    # an expert, lie on either side of a row-tile boundary (256-row tiles when an expert has > 512 rows, else 128) or in
+    # an expert's last partial tile -- where a tile-edge or clamp bug at the real K would show
+    bm = 256 if (n + E - 1) // E > 512 else 128
+    sample = torch.unique(torch.cat([torch.randperm(S, generator=torch.Generator().manual_seed(1))[:32],
+                                     edge_tokens(offs, perm_raw, 2, bm, seed=2, per_expert=4)]))
+    assert sample.numel() >= 40
     sub = {k: (v[sample] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == S else v) for k, v in ref.items()}
     cpu_experts = [mk[1](M, I).to(dtype) for _ in range(E)]
     for ce, ge in zip(cpu_experts, moe.deepspeed_moe.experts.deepspeed_experts):
@@ -452,7 +503,8 @@ def test_cfg3_phi_stack_32_layers():
                 out, l_aux, cnt = moe(h)
                 if keep is not None:
                     r = moe.deepspeed_moe.last_routing
-                    keep.append((h, out, float(l_aux), cnt.clone(), r.slot.clone(), r.expert_idx.clone()))
+                    keep.append((h, out, float(l_aux), cnt.clone(), r.slot.clone(), r.expert_idx.clone(),
+                                 r.expert_offsets.cpu().clone(), r.perm.cpu().clone()))
                 x = x + out
         return x
 
@@ -462,9 +514,9 @@ def test_cfg3_phi_stack_32_layers():
     torch.cuda.synchronize()
     assert torch.equal(y1, y2) and bool(torch.isfinite(y1.float()).all())
     sampled = {0, 10, 21, L - 1}
-    smp = torch.randperm(S, generator=torch.Generator().manual_seed(2))[:32]
+    smp0 = torch.randperm(S, generator=torch.Generator().manual_seed(2))[:24]
     dropped = 0
-    for l, (h, out, l_aux, cnt, slot, idx) in enumerate(kept):
+    for l, (h, out, l_aux, cnt, slot, idx, offs_l, perm_l) in enumerate(kept):
         moe = layers[l]
         lg = _ops().gate_logits(h.reshape(-1, M), moe.deepspeed_moe.gate.wg.weight).cpu()
         ref = ix.route_top2(lg, C)
@@ -472,6 +524,7 @@ def test_cfg3_phi_stack_32_layers():
         assert torch.equal(cnt.cpu(), ref["exp_counts"]) and abs(l_aux - float(ref["l_aux"])) <= 1e-5, f"layer {l}"
         dropped += int((ref["slot"] < 0).sum())
         if l in sampled:
+            smp = torch.unique(torch.cat([smp0, edge_tokens(offs_l, perm_l, 2, 256, seed=l, per_expert=2)]))
             sub = {k: (v[smp] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == S else v) for k, v in ref.items()}
             cpu_experts = [PhiMLPRef(M, I).to(torch.bfloat16) for _ in range(E)]
             for ce, ge in zip(cpu_experts, moe.deepspeed_moe.experts.deepspeed_experts):
