@@ -21,6 +21,18 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources and the header (what a profile of the library was taken on)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "moe_gfx950.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

@@ -107,6 +107,16 @@ struct Tile {
 // Diagnostic build only (cdna guide section 7, in-kernel stamps): per-wave cycle sums of the K-loop segments go to a
 // buffer of their own, never to an output.
 __device__ unsigned long long g_stamps[8 * 8 * 8];
+// in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): shader cycles (s_memtime) and the 100 MHz reference
+// (s_memrealtime) across the K loops of the stamped blocks' wave 0: clock = d_memtime / d_memrealtime * 100 MHz
+__device__ unsigned long long g_clk[8 * 2];
+__device__ __forceinline__ unsigned long long stamp_real() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
 #ifndef GEMM_STAMP_BASE
 #define GEMM_STAMP_BASE 1024  // first of the 8 stamped blocks
 #endif
@@ -348,7 +358,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
     for (int ks = 0; ks < KS; ++ks) koff[ks] = ((ks * 4 + fq) ^ xsw(fr)) * 8;
     const int w_off = BM * BK + (wn * WNT + fr) * BK;
 #ifdef GEMM_STAMPS
-    unsigned long long st_wait = 0, st_issue = 0, st_comp = 0, st_t0 = 0, st_begin = 0, st_loop_end = 0;
+    unsigned long long st_wait = 0, st_issue = 0, st_comp = 0, st_t0 = 0, st_begin = 0, st_loop_end = 0, st_rbegin = 0,
+                       st_rend = 0;
 #endif
 
     // K loop and register epilogue for a wave that owns MFW 16-row fragments starting at tile row row_off.  The two
@@ -381,6 +392,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         for (int s = 0; s < NS - 1; ++s)
             if (LOADS && !(staged && s == 0) && s < nkl) stage(s, s);
 #ifdef GEMM_STAMPS
+        st_rbegin = stamp_real();
         st_t0 = stamp(); st_begin = st_t0;
 #endif
         for (int kt = 0; kt < nkl; ++kt) {
@@ -485,6 +497,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
         }
 #ifdef GEMM_STAMPS
         st_loop_end = stamp();
+        st_rend = stamp_real();
 #endif
 
         if (cur.slot >= 0) {
@@ -725,6 +738,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void grouped_gemm_kernel(const GemmPar
             unsigned long long *o = g_stamps + ((blockIdx.x - GEMM_STAMP_BASE) * 8 + wave) * 8;
             o[0] = st_wait; o[1] = st_issue; o[2] = st_comp; o[3] = st_loop_end - st_begin; o[4] = st_end - st_loop_end;
             o[5] = nk; o[6] = st_begin - st_entry; o[7] = st_end;
+            if (wave == 0) {
+                g_clk[(blockIdx.x - GEMM_STAMP_BASE) * 2] = st_loop_end - st_begin;
+                g_clk[(blockIdx.x - GEMM_STAMP_BASE) * 2 + 1] = st_rend - st_rbegin;
+            }
         }
     }
 #endif
@@ -977,6 +994,9 @@ static int gemm_args_ok(const char *fn, const void *a, int64_t lda, int gather_s
 #ifdef GEMM_STAMPS
 extern "C" int moe_debug_read_stamps(unsigned long long *host_dst) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(moe::g_stamps), sizeof(unsigned long long) * 512);
+}
+extern "C" int moe_debug_read_clock(unsigned long long *host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(moe::g_clk), sizeof(unsigned long long) * 16);
 }
 #endif
 

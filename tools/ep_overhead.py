@@ -56,4 +56,18 @@ moe.deepspeed_moe._set_ep_group(dist.group.WORLD)
 for c in ("1", "2", "4", "8"):
     os.environ["MOE_EP_CHUNKS"] = c
     timeit(f"exchange path, {c} chunk(s), 1-rank RCCL")
+if os.environ.get("EP_PROFILE"):
+    import cProfile, pstats
+    os.environ["MOE_EP_CHUNKS"] = "1"
+    pr = cProfile.Profile()
+    with torch.no_grad():
+        for _ in range(5):
+            moe(x)
+        torch.cuda.synchronize()
+        pr.enable()
+        for _ in range(200):
+            moe(x)
+        pr.disable()
+        torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
 dist.destroy_process_group()

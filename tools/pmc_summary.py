@@ -37,5 +37,10 @@ for k, cs in agg.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "GRBM_GUI_ACTIVE" in e:
         e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8)   # 1024 SIMDs
     res[k.split("(")[0]] = e
+# which kernel sources these counters belong to: bench.py quotes `roofline.traffic` from this file only while the
+# sources are the ones that were profiled
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from moe_llava_amd.build import kernel_source_sha  # noqa: E402
+res["_meta"] = {"kernel_source_sha256": kernel_source_sha()}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
