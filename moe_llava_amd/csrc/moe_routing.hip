@@ -126,8 +126,28 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16_t *__restri
                                                           unsigned long long jitter_seed) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + wave) * R;
-    if (row0 >= S) return;
-    gate_rows<EMAX, R, WG16, DT, JIT>(x, wg, logits, S, M, E, row0, lane, jitter_seed);
+    // Small launches (S <= 4096: a few hundred blocks, each wave walking M in 4-5 dependent rounds of loads) are bound by
+    // the miss latency of a round, not by bandwidth: the block first touches every 128-byte line of wg and of its own
+    // rows of x, one dword per thread, so that all lines are in flight at once (see gate_route_fused_kernel; the words
+    // stay live until the impossible condition at the end).  Large launches skip this: they are bandwidth-bound.
+    unsigned touched = 0;
+    if (S <= 4096) {
+        const int wg_lines = (E * M * (WG16 ? 2 : 4)) >> 7;
+        const int blk_row0 = blockIdx.x * 4 * R;
+        const int blk_rows = min(4 * R, S - blk_row0);
+        const int n_lines = wg_lines + ((blk_rows * M * 2) >> 7);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = (int)threadIdx.x + q * 256;
+            if (i < n_lines) {
+                const char *ptr = i < wg_lines ? reinterpret_cast<const char *>(wg) + ((size_t)i << 7)
+                                             : reinterpret_cast<const char *>(x + (size_t)blk_row0 * M) + ((size_t)(i - wg_lines) << 7);
+                touched ^= *reinterpret_cast<const unsigned *>(ptr);
+            }
+        }
+    }
+    if (row0 < S) gate_rows<EMAX, R, WG16, DT, JIT>(x, wg, logits, S, M, E, row0, lane, jitter_seed);
+    if (touched == 0x9e3779b9u && S < 0) logits[0] = 0.f;  // never true: keeps the touch loads alive
 }
 
 // the jitter factors themselves, [S, M] fp32 (tests and inspection; the kernels never read such a tensor)
