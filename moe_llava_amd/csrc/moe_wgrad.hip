@@ -144,23 +144,42 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
         q = w / last;
         rem = (nb - 1) * g + (w - q * last);
     }
-    if (q >= E) return;  // never (grid = E * per_e); keeps the loops below in bounds
+    if (q >= E) {  // never (grid = E * per_e); keeps the loops below in bounds
+#ifdef MOE_DEBUG
+        __builtin_trap();
+#endif
+        return;
+    }
     int expert = q;
     if (E <= WG_LPT_MAX_E) {
-        // expert with rank q when sorted by rows, descending (ties: lower index first); all scalar work
+        // expert with rank q when sorted by rows, descending (ties: lower index first); all scalar work.  The row totals
+        // are taken once (G loads; the chunked expert-parallel backward passes C * ep groups per expert), then ranked in
+        // LDS -- the first version re-summed every expert's groups inside the ranking loop, O(E^2 * G / E) loads
+        // per block.
+        static_assert(WG_LPT_MAX_E <= 16, "row totals are kept in 16 LDS words");
+        __shared__ int s_rows[16];
         const int per = p.G / E;
+        if (threadIdx.x < 16) {
+            int r = -1;
+            if ((int)threadIdx.x < E) {
+                r = 0;
+                for (int src = 0; src < per; ++src)
+                    r += p.group_offsets[src * E + threadIdx.x + 1] - p.group_offsets[src * E + threadIdx.x];
+            }
+            s_rows[threadIdx.x] = r;
+        }
+        __syncthreads();
         int mine = -1;
-        for (int e = 0; e < E && mine < 0; ++e) {
-            int rows_e = 0;
-            for (int src = 0; src < per; ++src) rows_e += p.group_offsets[src * E + e + 1] - p.group_offsets[src * E + e];
+        for (int e = 0; e < E; ++e) {
+            const int re = s_rows[e];
             int rank = 0;
             for (int f = 0; f < E; ++f) {
-                int rows_f = 0;
-                for (int src = 0; src < per; ++src) rows_f += p.group_offsets[src * E + f + 1] - p.group_offsets[src * E + f];
-                rank += (rows_f > rows_e || (rows_f == rows_e && f < e)) ? 1 : 0;
+                const int rf = s_rows[f];
+                rank += (rf > re || (rf == re && f < e)) ? 1 : 0;
             }
             if (rank == q) mine = e;
         }
+        mine = __builtin_amdgcn_readfirstlane(mine);
         expert = mine;
     }
     const int per_sr = 4 * p.n_tiles;
@@ -169,7 +188,12 @@ __global__ __launch_bounds__(WTHREADS, 2) void wgrad_tn_kernel(const WgradParams
     const int rows_in = min(4, p.r_tiles - sr * 4);
     const int nt = rem2 / rows_in;
     const int rt = sr * 4 + (rem2 - nt * rows_in);
-    if (expert < 0 || expert >= p.n_experts) return;
+    if (expert < 0 || expert >= p.n_experts) {  // never: every rank 0 .. E-1 is taken by exactly one expert
+#ifdef MOE_DEBUG
+        __builtin_trap();
+#endif
+        return;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;

@@ -4,9 +4,12 @@ Keeps the reference-visible structure -- ``deepspeed_experts`` is an ``nn.Module
 the expert passed in, every parameter tagged ``allreduce=False`` / ``group_name`` (read by
 ``moellava/train/llava_trainer.py:822-824`` and ``llava_stablelm_moe.py:693-699``) -- while the grouped
 GEMM wants one contiguous ``[E_local, N, K]`` buffer per projection.  Both hold: the packed buffers are
-allocated once and every expert ``nn.Linear`` parameter is re-pointed to a *view* into them, so
-``state_dict()`` / ``load_state_dict()`` / in-place optimizer updates hit the packed memory directly.
-A cheap ``data_ptr`` check per forward re-packs after ``.to()`` / ``.cuda()`` replaced the storage.
+allocated once and every expert ``nn.Linear`` parameter that owns its memory is re-pointed to a *view* into
+them, so ``state_dict()`` / ``load_state_dict()`` / in-place optimizer updates hit the packed memory directly.
+Parameters that are views into somebody else's larger storage (an engine's flat buffer: DeepSpeed ZeRO-1/2) are
+NOT re-pointed: they stay where their owner put them and are copied into the packed buffers on every forward.
+A ``data_ptr`` check per forward re-packs after ``.to()`` / ``.cuda()`` replaced the storage; decode-size calls use
+the cheaper ``packed_unchanged()`` (identity and address of every parameter against the last full check).
 """
 from __future__ import annotations
 
