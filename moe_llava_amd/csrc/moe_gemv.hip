@@ -200,8 +200,12 @@ int launch_skinny_gemm(const GemmParams &p0, int epilogue, int max_rows, hipStre
     // while the launch still has a block for every CU (S = 1, two active experts: 10.5 us with 1 group, 16 with 2).
     int nw = 2;
     if (!gated) {
+        // ... and fills whole rounds of the 256 CUs at least as well as 1 group per block would (Phi fc2 at S = 32,
+        // N = 2560: 320 blocks of 2 groups ran 78.8 us, 640 blocks of 1 group 73 us; profiles/r03/skinny_knobs_r03j.txt)
         const long long active = p.G < max_rows ? p.G : max_rows;  // groups that can hold rows
-        nw = active * ((p.N_out + 31) / 32) >= 256 ? 2 : 1;
+        const long long b2 = active * ((p.N_out + 31) / 32), b1 = active * ((p.N_out + 15) / 16);
+        const long long r2 = (b2 + 255) / 256, r1 = (b1 + 255) / 256;
+        nw = (b2 >= 256 && b2 * r1 >= b1 * r2) ? 2 : 1;  // b2 / (256 r2) >= b1 / (256 r1)
         const int v = knobs().skinny_nw;  // tuning knob MOE_SKINNY_NW
         if (v == 1 || v == 2) nw = v;
     }

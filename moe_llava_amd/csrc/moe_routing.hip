@@ -71,6 +71,64 @@ __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const vo
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) acc[r][e] = 0.f;
 
+    // Every expert of the template's width by this wave (the usual case): one basic block per slice of M, so that the
+    // wg loads of all experts are issued together with the x loads and waited for as they are needed -- the general
+    // loop below asks per expert, and its run-time conditions made the compiler issue each expert's two loads only after
+    // the previous expert's FMAs (1 + E dependent memory round trips per slice).  The fmaf chain of a (row, expert)
+    // pair is the same in both loops.
+    constexpr int EF = EMAX <= 8 ? EMAX : 1;  // 16 experts: 252 registers, not taken
+    if (EMAX <= 8 && E == EMAX && e_step == 1) {
+#pragma unroll 1
+        for (int m0 = lane * 8; m0 < M; m0 += 64 * 8) {
+            uint4 xq[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int row = row0 + r;
+                if (row > S - 1) row = S - 1;
+                xq[r] = *reinterpret_cast<const uint4 *>(x + (size_t)row * M + m0);
+            }
+            uint4 wq[EF];
+            float4 wa[EF], wb[EF];
+#pragma unroll
+            for (int e = 0; e < EF; ++e) {
+                if (WG16) {
+                    wq[e] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(wg) + (size_t)e * M + m0);
+                } else {
+                    wa[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(wg) + (size_t)e * M + m0);
+                    wb[e] = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(wg) + (size_t)e * M + m0 + 4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the loads above stay together, ahead of the arithmetic
+            float xf[R][8];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                unpack8_t<DT>(xq[r], xf[r]);
+                if (JIT) {
+                    int row = row0 + r;
+                    if (row > S - 1) row = S - 1;
+                    float jf[8];
+                    jitter4(jitter_seed, row, m0, jf);
+                    jitter4(jitter_seed, row, m0 + 4, jf + 4);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xf[r][j] *= jf[j];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EF; ++e) {
+                float w[8];
+                if (WG16) {
+                    unpack8_t<DT>(wq[e], w);
+                } else {
+                    w[0] = wa[e].x; w[1] = wa[e].y; w[2] = wa[e].z; w[3] = wa[e].w;
+                    w[4] = wb[e].x; w[5] = wb[e].y; w[6] = wb[e].z; w[7] = wb[e].w;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[r][e] = fmaf(xf[r][j], w[j], acc[r][e]);
+            }
+        }
+    } else {
 #ifndef GATE_UNROLL
 #define GATE_UNROLL 1
 #endif
@@ -108,6 +166,7 @@ __device__ __forceinline__ void gate_rows(const bf16_t *__restrict__ x, const vo
                     for (int j = 0; j < 8; ++j) acc[r][e] = fmaf(xf[r][j], w[j], acc[r][e]);
             }
         }
+    }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)

@@ -30,6 +30,7 @@ ap.add_argument("--cold", type=int, default=1, help="weight copies cycled per ca
 ap.add_argument("--gelu", type=int, default=0, help="fc1 = Phi form: W1 [E, I, M] + bias, gelu_new epilogue (default: gated SwiGLU, W1 [E, 2I, M])")
 ap.add_argument("--splitk", type=int, default=1, help="1: pass a split-K workspace (product behaviour), 0: none")
 ap.add_argument("--pad", type=int, default=0, help="pad leading dims of x / h (and the w buffers, for -DGEMM_EXP_LDW_PAD builds)")
+ap.add_argument("--active", type=int, default=0, help="decode-size runs: spread the rows evenly over the first N experts only")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
@@ -47,6 +48,8 @@ if a.skew:
 else:
     frac = torch.ones(E) / E
 cnt = (frac / frac.sum() * R).long(); cnt[-1] = R - cnt[:-1].sum()
+if a.active:
+    cnt = torch.zeros(E, dtype=torch.long); cnt[:a.active] = R // a.active; cnt[a.active - 1] += R - cnt.sum()
 offs = torch.zeros(E + 1, dtype=torch.int32); offs[1:] = torch.cumsum(cnt, 0).int(); offs = offs.to(dev)
 perm = (torch.arange(R, device=dev) if a.sorted else torch.randperm(R, device=dev)).int()
 h = torch.empty(R, I + P, dtype=torch.bfloat16, device=dev)
