@@ -327,6 +327,8 @@ class MOELayer(nn.Module):
             # its inference loader (moellava/model/builder.py:70,475; serve/cli.py:67-69): both run, nothing else does
             raise TypeError(f"MoE block runs in bf16 or fp16; got {x_in.dtype}")
         wg = self.gate.wg.weight
+        if x_in.numel() == 0:
+            return self._empty_forward(x_in, wg)
         if torch.is_grad_enabled():
             params = self.experts.param_list()
             if x_in.requires_grad or wg.requires_grad or any(p.requires_grad for p in params):
@@ -341,6 +343,19 @@ class MOELayer(nn.Module):
             out, l_aux, _ = self._run(x_in, used_token, save=False)
         self.__dict__["l_aux"] = l_aux
         return out
+
+    def _empty_forward(self, x_in: Tensor, wg: Tensor) -> Tensor:
+        """A call without tokens ([0, T, M] or [B, 0, M]).  Upstream's gating runs on the empty logits: every count is
+        0, `l_aux` is a mean over zero tokens (NaN), the experts see only empty capacity slots, the output is empty.
+        Nothing is launched.  With expert parallelism the other ranks' rows would still have to be served: refused
+        loudly instead of leaving the group waiting in its all-to-all."""
+        if not (self.ep_size == 1 and not (self.force_exchange and self.ep_group is not None)):
+            raise RuntimeError("MoE block: a rank without tokens cannot take part in the expert-parallel exchange")
+        d = self.__dict__
+        d["exp_counts"] = torch.zeros(wg.shape[0], dtype=torch.int64, device=x_in.device)
+        d["last_routing"] = None
+        d["l_aux"] = torch.full((), float("nan"), dtype=torch.float32, device=x_in.device)
+        return x_in * 0 if (torch.is_grad_enabled() and x_in.requires_grad) else torch.empty_like(x_in)
 
     def _run(self, x_in: Tensor, used_token, save: bool):
         """gate -> routing -> grouped expert FFN (through the all-to-all when ep_size > 1) -> combine.

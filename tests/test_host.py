@@ -160,6 +160,27 @@ def test_no_gpu_means_loud_failure_not_fallback():
         moe(torch.zeros(1, 8, 64, dtype=torch.bfloat16))
 
 
+@pytest.mark.parametrize("shape", [(0, 7, 64), (3, 0, 64)])
+def test_call_without_tokens_matches_the_literal_oracle(shape):
+    """No tokens: nothing to launch, so this runs without a GPU.  Same result as upstream's gating on empty logits
+    (oracle/ds_moe_literal.py): empty output, zero counts, NaN `l_aux` (a mean over zero tokens)."""
+    mine = moe_llava_amd.MoE(64, StableLMMLP(64, 128), num_experts=4, k=2, capacity_factor=1.5).to(torch.bfloat16)
+    ref = lit.MoERef(64, StableLMMLP(64, 128), num_experts=4, k=2, capacity_factor=1.5).to(torch.bfloat16)
+    ref.deepspeed_moe.gate.noise = torch.zeros(0, 4)   # the Gumbel noise of zero tokens
+    x = torch.zeros(shape, dtype=torch.bfloat16)
+    for train in (False, True):
+        mine.train(train); ref.train(train)
+        xm = x.clone().requires_grad_(train)
+        out, l_aux, cnt = mine(xm)
+        r_out, r_laux, r_cnt = ref(x.clone())
+        assert out.shape == r_out.shape == x.shape and out.dtype == r_out.dtype
+        assert torch.isnan(l_aux) and torch.isnan(r_laux) and l_aux.dtype == r_laux.dtype
+        assert cnt.dtype == r_cnt.dtype and cnt.tolist() == r_cnt.tolist() == [0, 0, 0, 0]
+        if train:
+            out.sum().backward()
+            assert xm.grad.shape == x.shape
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "moe_llava_amd")
     for fn in os.listdir(pkg):
