@@ -1,4 +1,4 @@
-# usage: tools/_prof_quick.sh TAG bench-args...   -> kernel stats (top kernels) of one bench.py run
+# usage: tools/prof_quick.sh TAG bench-args...   -> kernel stats (top kernels) of one bench.py run
 TAG=$1; shift; R=$PWD
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pq_$TAG -o t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-train --no-other-configs "$@" > /dev/null 2>&1 || exit 1

@@ -1,3 +1,4 @@
+# split-K tail on / off under rocprofv3 for Phi fc1, config 1 fc1, config 4 (-> profiles/r03/splitk_*.txt)
 cd /tmp; export TMPDIR=/tmp
 R=/root/repo
 for cfg in "phi --M 2560 --I 10240 --rows 27424 --gelu 1 --shape fc1" "c1 --rows 1408 --cold 12 --shape fc1" "c4 --rows 4864 --I 5504 --cold 5 --shape both"; do
