@@ -22,6 +22,7 @@ struct Knobs {
     bool no_persist;           // MOE_NO_PERSIST
     bool no_skinny;            // MOE_NO_SKINNY: decode-size launches through the tiled kernel
     bool no_gate_route_fusion; // MOE_NO_GATE_ROUTE_FUSION
+    bool no_gate_stream;       // MOE_NO_GATE_STREAM: large-S gate GEMV through gate_logits_kernel (A/B, tests)
     int skinny_nw, skinny_ks;  // MOE_SKINNY_NW / MOE_SKINNY_KS (0 = rule)
     int splitk;                // MOE_SPLITK: largest split factor of the split-K tail (0 or 1 = off; default 8)
     int splitk_min;            // MOE_SPLITK_MIN: fewest K slices per piece (0 = the default, 24)

@@ -209,6 +209,107 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const bf16_t *__restri
     if (touched == 0x9e3779b9u && S < 0) logits[0] = 0.f;  // never true: keeps the touch loads alive
 }
 
+// Large S (> 4096 tokens), M = NSL x 512, every expert of the template's width, no jitter: the streaming form.
+// gate_logits_kernel walks a row group's M in NSL dependent rounds of loads (x from HBM, wg from L1 / L2) and ran at
+// ~3 TB/s of x.  Here one persistent block per CU keeps wg in LDS as fp32 (filled once; conflict-free planes of 16 B per
+// lane), and every wave has ALL loads of its current row pair and of its next one in flight (2 x NSL x 2 KiB) while it
+// does the FMAs of the current pair.  A (row, expert) sum is the same fmaf chain over the lane's 8-element
+// pieces in ascending M, then the same wave butterfly: bit-identical to gate_rows.
+// Bound: HBM, S * M * 2 bytes.
+constexpr int GATE_STREAM_THREADS = 512;
+template <int EMAX, bool WG16, int DT, int NSL, int R>
+__global__ __launch_bounds__(GATE_STREAM_THREADS) void gate_logits_stream_kernel(const bf16_t *__restrict__ x,
+                                                                                  const void *__restrict__ wg,
+                                                                                  float *__restrict__ logits, int S) {
+    constexpr int M = NSL * 512;  // R rows per wave and step: 2 at M = 2048, 1 at M = 2560 (registers)
+    __shared__ __attribute__((aligned(16))) float4 s_wg[EMAX * NSL * 2 * 64];  // [e][slice][half][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_pairs = (S + R - 1) / R;
+    const int stride = (int)gridDim.x * (GATE_STREAM_THREADS / 64);
+    int pair = (int)blockIdx.x * (GATE_STREAM_THREADS / 64) + wave;
+    auto load_pair = [&](int pr, uint4 (&q)[NSL][R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int row = pr * R + r;
+            if (row > S - 1) row = S - 1;  // clamped, stored only when < S
+            const bf16_t *src = x + (size_t)row * M + lane * 8;
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) q[i][r] = *reinterpret_cast<const uint4 *>(src + i * 512);
+        }
+    };
+    // two register buffers, the loop unrolled by two so that neither is indexed dynamically.  The first rows' loads go
+    // out before the LDS fill: they do not depend on it, and the fill + barrier is 2-3 us of an idle memory system
+    uint4 qa[NSL][R], qb[NSL][R];
+    const bool has0 = pair < n_pairs;  // wave-uniform
+    if (has0) load_pair(pair, qa);
+    for (int q = tid; q < EMAX * NSL * 64; q += GATE_STREAM_THREADS) {
+        const int l = q & 63, es = q >> 6;  // es = e * NSL + slice
+        const int e = es / NSL, i = es - e * NSL;
+        const size_t src = (size_t)e * M + i * 512 + l * 8;
+        float w[8];
+        if (WG16) {
+            unpack8_t<DT>(*reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(wg) + src), w);
+        } else {
+            const float4 a = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(wg) + src);
+            const float4 b = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(wg) + src + 4);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        }
+        s_wg[(es * 2 + 0) * 64 + l] = make_float4(w[0], w[1], w[2], w[3]);
+        s_wg[(es * 2 + 1) * 64 + l] = make_float4(w[4], w[5], w[6], w[7]);
+    }
+    __syncthreads();
+    if (!has0) return;  // (after the only barrier)
+    auto compute_pair = [&](int pr, const uint4 (&q)[NSL][R]) {
+        float acc[R][EMAX];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) acc[r][e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            float xf[R][8];
+#pragma unroll
+            for (int r = 0; r < R; ++r) unpack8_t<DT>(q[i][r], xf[r]);
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const float4 wa = s_wg[((e * NSL + i) * 2 + 0) * 64 + lane];
+                const float4 wb = s_wg[((e * NSL + i) * 2 + 1) * 64 + lane];
+                const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[r][e] = fmaf(xf[r][j], w[j], acc[r][e]);
+            }
+            // wg is the same for every row pair, so the compiler keeps all of it in registers across the loop (E x M / 64
+            // = 128 registers at E = 4, M = 2048, 160 at M = 2560): no LDS reads are left in the loop; LDS is how the
+            // waves get wg without every one of them pulling it through L1 / L2.  That is also why the form stops at
+            // E = 4: 8 experts would be 256+ registers (the compiler spilled 250-580 of them in every arrangement tried).
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const float v = wave_sum(acc[r][e]);
+                if (lane == 0 && pr * R + r < S) logits[(size_t)(pr * R + r) * EMAX + e] = v;
+            }
+    };
+    while (true) {
+        const int p1 = pair + stride;
+        const bool has1 = p1 < n_pairs;  // wave-uniform
+        if (has1) load_pair(p1, qb);
+        __builtin_amdgcn_sched_barrier(0);  // the next pair's loads are issued before this pair's arithmetic
+        compute_pair(pair, qa);
+        if (!has1) break;
+        const int p2 = p1 + stride;
+        const bool has2 = p2 < n_pairs;
+        if (has2) load_pair(p2, qa);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_pair(p1, qb);
+        if (!has2) break;
+        pair = p2;
+    }
+}
+
 // the jitter factors themselves, [S, M] fp32 (tests and inspection; the kernels never read such a tensor)
 __global__ __launch_bounds__(256) void jitter_fill_kernel(unsigned long long seed, int S, int M, float *__restrict__ out) {
     const long long q = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread = 4 columns of one token
@@ -787,6 +888,7 @@ void read_knobs(Knobs &k) {
     k.no_persist = getenv("MOE_NO_PERSIST") != nullptr;
     k.no_skinny = getenv("MOE_NO_SKINNY") != nullptr;
     k.no_gate_route_fusion = getenv("MOE_NO_GATE_ROUTE_FUSION") != nullptr;
+    k.no_gate_stream = getenv("MOE_NO_GATE_STREAM") != nullptr;
     if (const char *env = getenv("MOE_SKINNY_NW")) k.skinny_nw = atoi(env);
     if (const char *env = getenv("MOE_SKINNY_KS")) k.skinny_ks = atoi(env);
     if (const char *env = getenv("MOE_SPLITK")) k.splitk = atoi(env);
@@ -857,6 +959,23 @@ extern "C" int moe_gate_logits_fwd(const void *x, const void *wg, int wg_dtype, 
             if (wg16) LAUNCH_GATE_T(EM, RR, true, DT_F16); else LAUNCH_GATE_T(EM, RR, false, DT_F16);            \
         }                                                                                                        \
     } while (0)
+    // large S at the widths of the reference's models: the streaming form (persistent blocks, wg in LDS)
+    // (not fp16 activations with an fp16 gate weight: there the compiler turns pairs of gate_rows' FMAs into
+    // v_dot2c_f32_f16, which rounds differently from the FMAs on the fp32 copy of wg that the streaming form keeps in
+    // LDS, and the two forms must give the same logits bit for bit)
+    if (S > 4096 && !jseed && (M == 2048 || M == 2560) && E == 4 && !(wg16 && dtype == MOE_DTYPE_F16) &&
+        !knobs().no_gate_stream) {
+        dim3 grid(256);  // one block per CU; each of its 8 waves strides over the row pairs
+#define LAUNCH_GS(W16, DT_, NSL_, R_)                                                                                  \
+        hipLaunchKernelGGL((gate_logits_stream_kernel<4, W16, DT_, NSL_, R_>), grid, dim3(GATE_STREAM_THREADS), 0, st, xp, wg, \
+                           logits, S)
+#define LAUNCH_GS_M(W16, DT_) do { if (M == 2048) LAUNCH_GS(W16, DT_, 4, 2); else LAUNCH_GS(W16, DT_, 5, 1); } while (0)
+        if (dtype == MOE_DTYPE_BF16) { if (wg16) LAUNCH_GS_M(true, DT_BF16); else LAUNCH_GS_M(false, DT_BF16); }
+        else LAUNCH_GS_M(false, DT_F16);
+#undef LAUNCH_GS_M
+#undef LAUNCH_GS
+        return check_launch("gate_logits_stream_kernel");
+    }
     // small S: 2 rows per wave so that the grid covers more CUs (24 vs 28 us gate + routing at S = 704); large S: 4
     // rows per wave (8 measured no better)
     if (S <= 2048) { if (E <= 4) LAUNCH_GATE(4, 2); else if (E <= 8) LAUNCH_GATE(8, 2); else if (E <= 16) LAUNCH_GATE(16, 2); else LAUNCH_GATE(64, 1); }

@@ -118,6 +118,28 @@ def test_gate_logits_numerics(S, M, E, wg_dtype):
     assert torch.allclose(got, ref32, atol=tol, rtol=0)
 
 
+@pytest.mark.parametrize("dtype,wg_dtype", [(torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                            (torch.float16, torch.float32), (torch.float16, torch.float16)])
+@pytest.mark.parametrize("S,M", [(4097, 2048), (22528, 2048), (13712, 2560), (4099, 2560), (9001, 2048)])
+def test_gate_logits_streaming_form_is_bit_identical_and_accurate(S, M, dtype, wg_dtype):
+    """Large S at M = 2048 / 2560 with 4 experts runs `gate_logits_stream_kernel` (persistent blocks, gate weight in LDS):
+    the same logits bit for bit as the general kernel (MOE_NO_GATE_STREAM=1), which the routing parity relies on, and
+    within the GEMV tolerance of fp64; odd S covers the clamped last row and waves without rows.  (fp16 activations with
+    an fp16 gate weight stay on the general kernel, whose FMAs the compiler pairs into v_dot2c_f32_f16.)"""
+    ops = _ops()
+    E = 4
+    g = torch.Generator().manual_seed(S + M)
+    x = torch.randn(S, M, generator=g).to(dtype).to(DEV)
+    wg = (torch.randn(E, M, generator=g) * 0.02).to(wg_dtype).to(DEV)
+    got = ops.gate_logits(x, wg)
+    with knob("MOE_NO_GATE_STREAM", "1"):
+        general = ops.gate_logits(x, wg)
+    assert torch.equal(got, general)
+    ref = x.cpu().double() @ wg.cpu().double().t()
+    tol = 1e-5 * float(ref.abs().max()) + 2e-6 * (M ** 0.5)
+    assert float((got.cpu().double() - ref).abs().max()) <= tol
+
+
 def _mk_experts(kind, M, I, E, seed, scale=0.05, dtype=torch.bfloat16):
     g = torch.Generator().manual_seed(seed)
     mk = {"stablelm": lambda: StableLMMLPRef(M, I), "phi": lambda: PhiMLPRef(M, I),
