@@ -93,6 +93,34 @@ def test_routing_ties_and_extremes():
     _check_routing(lg, lit.capacity_of(S, E, 3.0, 0))
 
 
+def test_routing_fuzz_vs_index_oracle():
+    """120 seeded random configurations against the index oracle, every field bit-exact: token counts around the kernels'
+    own boundaries (64 / 1024 / 4096 tokens: one-launch decode form, single-block form, three-kernel form), odd expert
+    counts, capacity factors from starving to no-drop, min_capacity, quantised logits (exact ties), skewed logits
+    (overflowing experts), injected Gumbel noise, drop_tokens on and off."""
+    import random
+    rnd = random.Random(20240611)
+    edges = [1, 2, 3, 63, 64, 65, 127, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097]
+    for case in range(120):
+        S = rnd.choice(edges) if rnd.random() < 0.5 else rnd.randint(1, 6000)
+        E = rnd.choice([2, 3, 4, 4, 4, 5, 7, 8, 8, 12, 16, 17, 33, 64])
+        g = torch.Generator().manual_seed(1000 + case)
+        logits = torch.randn(S, E, generator=g) * rnd.choice([0.1, 1.0, 1.0, 4.0, 30.0])
+        kind = rnd.random()
+        if kind < 0.25:
+            logits = (logits * 2).round() / 2                     # exact ties between experts
+        elif kind < 0.5:
+            logits[: max(1, S // 2), rnd.randrange(E)] += 2.5     # one expert overflows its capacity
+        noise = lit.gumbel_noise((S, E), 7 + case) if rnd.random() < 0.5 else None
+        drop = rnd.random() < 0.8
+        cf = rnd.choice([0.1, 0.5, 1.0, 1.25, 1.5, 2.0, 4.0])
+        C = lit.capacity_of(S, E, cf * 2, rnd.choice([0, 0, 4, 17])) if drop else 0
+        try:
+            _check_routing(logits, C, noise, drop)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: S={S} E={E} cf={cf} C={C} drop={drop} noisy={noise is not None} kind={kind:.2f}: {e}")
+
+
 def test_capacity_host_formula_matches_oracle():
     from moe_llava_amd.sharded_moe import capacity_of
     for S in (1, 3, 5, 7, 704, 705, 2432, 22528, 54848, 131072):

@@ -65,6 +65,39 @@ def test_top1_used_token_rsample_nodrop_and_ties():
     _check(torch.zeros(S, E), C, u)                          # all logits equal: every token picks expert 0
 
 
+def test_top1_routing_fuzz_vs_index_oracle():
+    """80 seeded random top-1 configurations against the index oracle, bit-exact: sizes around the kernels' boundaries, odd
+    expert counts, RTS on / off (coarse uniforms give ties), `used_token` masks, RSample noise, starving capacities,
+    drop_tokens off."""
+    import random
+    rnd = random.Random(777)
+    edges = [1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 4097]
+    for case in range(80):
+        S = rnd.choice(edges) if rnd.random() < 0.5 else rnd.randint(1, 7000)
+        E = rnd.choice([2, 3, 4, 4, 5, 8, 8, 13, 16, 64])
+        g = torch.Generator().manual_seed(5000 + case)
+        logits = torch.randn(S, E, generator=g) * rnd.choice([0.2, 1.0, 1.0, 5.0])
+        if rnd.random() < 0.4:
+            logits[:, rnd.randrange(E)] += 1.5
+        if rnd.random() < 0.2:
+            logits = logits.round()
+        u = None
+        if rnd.random() < 0.6:
+            u = torch.rand(S, E, generator=g)
+            if rnd.random() < 0.3:
+                u = (u * 8).floor() / 8
+        used = (torch.rand(S, generator=g) > 0.25).long() if rnd.random() < 0.4 else None
+        noise = lit.gumbel_noise((S, E), 31 + case) if rnd.random() < 0.3 else None
+        drop = rnd.random() < 0.85
+        cf = rnd.choice([0.05, 0.25, 0.5, 1.0, 1.5, 3.0])
+        C = lit.capacity_of(S, E, cf, rnd.choice([0, 0, 4, 9])) if drop else 0
+        try:
+            _check(logits, C, u, used, noise, drop)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: S={S} E={E} cf={cf} C={C} drop={drop} rts={u is not None} "
+                                 f"used={used is not None} noisy={noise is not None}: {e}")
+
+
 def test_top1_in_kernel_random_numbers():
     from moe_llava_amd import ops
     S, E = 8192, 4
