@@ -247,6 +247,24 @@ def test_moe_layer_vs_literal_oracle(kind, M, I, E, shape, cf, noisy):
         assert float(out.cpu().reshape(-1, M)[dead].float().abs().max()) == 0.0
 
 
+def test_moe_layer_fuzz_vs_literal_oracle():
+    """24 seeded random blocks (all expert kinds, token counts from a decode step to several row tiles, starving to
+    generous capacity, with and without the Gumbel second choice) through the same check as above."""
+    import random
+    rnd = random.Random(99)
+    for case in range(24):
+        kind = rnd.choice(["stablelm", "phi", "qwen", "qwen_bias"])
+        M, I, E = rnd.choice([64, 128, 256]), rnd.choice([64, 192, 320]), rnd.choice([2, 4, 4, 8])
+        B = rnd.choice([1, 2, 3])
+        T = rnd.choice([1, 2, 7, 31, 33, 64, 65, 129, 257, 300])
+        cf = rnd.choice([0.25, 0.5, 1.0, 1.5, 2.0])
+        noisy = rnd.random() < 0.5
+        try:
+            test_moe_layer_vs_literal_oracle(kind, M, I, E, (B, T), cf, noisy)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {kind} M{M} I{I} E{E} shape {(B, T)} cf {cf} noisy {noisy}: {e}")
+
+
 @pytest.mark.parametrize("kind,M,I,E,shape,cf,wg16", [
     ("stablelm", 128, 320, 4, (3, 111), 1.5, False),
     ("stablelm", 256, 384, 4, (1, 5), 1.0, True),          # decode size: the weight-streaming kernel
