@@ -25,8 +25,8 @@ def _cmp(name, got, want, tol=2e-2):
     assert nrm <= tol, name
 
 
-def _run_both(kind, M, I, E, shape, cf, noisy, seed=11, aux_coef=0.3):
-    ref, mine, x = _build_pair(kind, M, I, E, shape, cf, seed=seed, noisy=noisy)
+def _run_both(kind, M, I, E, shape, cf, noisy, seed=11, aux_coef=0.3, use_residual=False):
+    ref, mine, x = _build_pair(kind, M, I, E, shape, cf, seed=seed, noisy=noisy, use_residual=use_residual)
     S = x.numel() // M
     if noisy:
         noise = lit.gumbel_noise((S, E), 99)
@@ -115,6 +115,26 @@ def test_jitter_policy_gradients_vs_oracle_autograd(kind, M, I, E, shape, cf):
     rp = dict(ref.deepspeed_moe.experts.named_parameters())
     for name, p in mine.deepspeed_moe.experts.named_parameters():
         _cmp(f"{tag} {name}", p.grad, rp[name].grad)
+
+
+@pytest.mark.parametrize("kind,M,I,E,shape", [("stablelm", 128, 320, 4, (2, 90)), ("phi", 64, 128, 2, (1, 150))])
+def test_residual_moe_forward_and_gradients_vs_oracle(kind, M, I, E, shape):
+    """`use_residual=True` (`MoE.forward`'s blend `out * c[..., :1] + mlp(x) * c[..., 1:]`, c =
+    softmax(coefficient(x))): the dense branch and the blend run as the reference's own torch modules around the HIP
+    block; output and every gradient (x through all three branches, `coefficient`, `mlp`, gate, experts) against the
+    oracle."""
+    ref, mine, xg, xr, out, r_out = _run_both(kind, M, I, E, shape, 1.5, False, seed=21, use_residual=True)
+    assert mine.mlp is not mine.deepspeed_moe.experts.deepspeed_experts[0]
+    tag = f"residual {kind}"
+    _cmp(tag + " out", out, r_out, tol=1e-2)
+    _cmp(tag + " dx", xg.grad, xr.grad)
+    rp = dict(ref.named_parameters())
+    seen = set()
+    for name, p in mine.named_parameters():
+        assert p.grad is not None, name
+        _cmp(f"{tag} {name}", p.grad, rp[name].grad, tol=3e-2 if name.startswith("coefficient") else 2e-2)
+        seen.add(name.split(".")[0])
+    assert {"coefficient", "mlp", "deepspeed_moe"} <= seen
 
 
 def test_training_forward_equals_inference_forward():

@@ -181,22 +181,29 @@ def _mk_experts(kind, M, I, E, seed, scale=0.05, dtype=torch.bfloat16):
     return exps
 
 
-def _build_pair(kind, M, I, E, S_shape, cf, seed, noisy=False, training=True, dtype=torch.bfloat16):
+def _build_pair(kind, M, I, E, S_shape, cf, seed, noisy=False, training=True, dtype=torch.bfloat16, use_residual=False):
     """(oracle MoERef on CPU, product MoE on GPU) with identical parameters."""
+    import copy
     import moe_llava_amd
     exps = _mk_experts(kind, M, I, E, seed, dtype=dtype)
     ref = lit.MoERef(M, exps[0], num_experts=E, k=2, capacity_factor=cf, eval_capacity_factor=2.0,
-                     min_capacity=0, top2_2nd_expert_sampling=noisy)
+                     min_capacity=0, top2_2nd_expert_sampling=noisy, use_residual=use_residual)
+    if use_residual:
+        ref.coefficient.to(dtype)
     for dst, src in zip(ref.deepspeed_moe.experts.deepspeed_experts, exps):
         dst.load_state_dict(src.state_dict())
     g = torch.Generator().manual_seed(seed + 100)
     ref.deepspeed_moe.gate.wg.weight.data = torch.randn(E, M, generator=g) * 0.1
-    mine = moe_llava_amd.MoE(M, exps[0], num_experts=E, k=2, capacity_factor=cf, eval_capacity_factor=2.0,
-                             min_capacity=0, top2_2nd_expert_sampling=noisy)
+    # (residual mode keeps the prototype itself as `.mlp`, upstream's "same object, not a copy": each side gets its own)
+    mine = moe_llava_amd.MoE(M, copy.deepcopy(exps[0]) if use_residual else exps[0], num_experts=E, k=2, capacity_factor=cf,
+                             eval_capacity_factor=2.0, min_capacity=0, top2_2nd_expert_sampling=noisy, use_residual=use_residual)
     missing = mine.load_state_dict(ref.state_dict(), strict=True)      # checkpoint-key ABI (SURVEY 8b)
     assert not missing.missing_keys and not missing.unexpected_keys
     for m in mine.deepspeed_moe.experts.deepspeed_experts:
         m.to(dtype)
+    if use_residual:
+        mine.coefficient.to(dtype)
+        mine.mlp.to(dtype)
     mine = mine.to(DEV)
     ref.train(training)
     mine.train(training)
