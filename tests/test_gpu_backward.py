@@ -25,8 +25,13 @@ def _cmp(name, got, want, tol=2e-2):
     assert nrm <= tol, name
 
 
-def _run_both(kind, M, I, E, shape, cf, noisy, seed=11, aux_coef=0.3, use_residual=False):
-    ref, mine, x = _build_pair(kind, M, I, E, shape, cf, seed=seed, noisy=noisy, use_residual=use_residual)
+def _run_both(kind, M, I, E, shape, cf, noisy, seed=11, aux_coef=0.3, use_residual=False, drop_tokens=True, skew=0.0):
+    ref, mine, x = _build_pair(kind, M, I, E, shape, cf, seed=seed, noisy=noisy, use_residual=use_residual,
+                               drop_tokens=drop_tokens)
+    if skew:                                         # push the tokens towards expert 0: its capacity share overflows
+        for m in (ref, mine):
+            m.deepspeed_moe.gate.wg.weight.data[0] += skew * torch.sign(m.deepspeed_moe.gate.wg.weight.data[0])
+        x = (x.float().abs() * torch.sign(ref.deepspeed_moe.gate.wg.weight.data[0])).to(x.dtype)
     S = x.numel() // M
     if noisy:
         noise = lit.gumbel_noise((S, E), 99)
@@ -135,6 +140,23 @@ def test_residual_moe_forward_and_gradients_vs_oracle(kind, M, I, E, shape):
         _cmp(f"{tag} {name}", p.grad, rp[name].grad, tol=3e-2 if name.startswith("coefficient") else 2e-2)
         seen.add(name.split(".")[0])
     assert {"coefficient", "mlp", "deepspeed_moe"} <= seen
+
+
+@pytest.mark.parametrize("kind,M,I,E,shape,noisy", [("stablelm", 128, 192, 4, (2, 150), False), ("phi", 64, 128, 8, (1, 333), True)])
+def test_drop_tokens_false_forward_and_gradients_vs_oracle(kind, M, I, E, shape, noisy):
+    """`drop_tokens=False`: the capacity becomes the busiest expert's count, nobody is dropped, although
+    the capacity factor alone (0.25) would drop most of expert 0's tokens.  Block output and gradients against the oracle."""
+    ref, mine, xg, xr, out, r_out = _run_both(kind, M, I, E, shape, 0.25, noisy, seed=33, drop_tokens=False, skew=0.3)
+    r = mine.deepspeed_moe.last_routing
+    S = xg.numel() // M
+    assert int((r.slot.cpu() < 0).sum()) == 0 and int(r.kept_counts.cpu().sum()) == 2 * S
+    assert int(r.exp_counts.cpu().max()) > -(-S // E)            # an expert holds more than an even share
+    tag = f"no-drop {kind}"
+    _cmp(tag + " out", out, r_out, tol=1e-2)
+    _cmp(tag + " dx", xg.grad, xr.grad)
+    rp = dict(ref.named_parameters())
+    for name, p in mine.named_parameters():
+        _cmp(f"{tag} {name}", p.grad, rp[name].grad)
 
 
 def test_training_forward_equals_inference_forward():

@@ -181,13 +181,14 @@ def _mk_experts(kind, M, I, E, seed, scale=0.05, dtype=torch.bfloat16):
     return exps
 
 
-def _build_pair(kind, M, I, E, S_shape, cf, seed, noisy=False, training=True, dtype=torch.bfloat16, use_residual=False):
+def _build_pair(kind, M, I, E, S_shape, cf, seed, noisy=False, training=True, dtype=torch.bfloat16, use_residual=False,
+                drop_tokens=True):
     """(oracle MoERef on CPU, product MoE on GPU) with identical parameters."""
     import copy
     import moe_llava_amd
     exps = _mk_experts(kind, M, I, E, seed, dtype=dtype)
     ref = lit.MoERef(M, exps[0], num_experts=E, k=2, capacity_factor=cf, eval_capacity_factor=2.0,
-                     min_capacity=0, top2_2nd_expert_sampling=noisy, use_residual=use_residual)
+                     min_capacity=0, top2_2nd_expert_sampling=noisy, use_residual=use_residual, drop_tokens=drop_tokens)
     if use_residual:
         ref.coefficient.to(dtype)
     for dst, src in zip(ref.deepspeed_moe.experts.deepspeed_experts, exps):
@@ -196,7 +197,8 @@ def _build_pair(kind, M, I, E, S_shape, cf, seed, noisy=False, training=True, dt
     ref.deepspeed_moe.gate.wg.weight.data = torch.randn(E, M, generator=g) * 0.1
     # (residual mode keeps the prototype itself as `.mlp`, upstream's "same object, not a copy": each side gets its own)
     mine = moe_llava_amd.MoE(M, copy.deepcopy(exps[0]) if use_residual else exps[0], num_experts=E, k=2, capacity_factor=cf,
-                             eval_capacity_factor=2.0, min_capacity=0, top2_2nd_expert_sampling=noisy, use_residual=use_residual)
+                             eval_capacity_factor=2.0, min_capacity=0, top2_2nd_expert_sampling=noisy, use_residual=use_residual,
+                             drop_tokens=drop_tokens)
     missing = mine.load_state_dict(ref.state_dict(), strict=True)      # checkpoint-key ABI
     assert not missing.missing_keys and not missing.unexpected_keys
     for m in mine.deepspeed_moe.experts.deepspeed_experts:
