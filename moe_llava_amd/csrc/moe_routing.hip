@@ -260,26 +260,38 @@ __global__ __launch_bounds__(GATE_STREAM_THREADS) void gate_logits_stream_kernel
     __syncthreads();
     if (!has0) return;  // (after the only barrier)
     auto compute_pair = [&](int pr, const uint4 (&q)[NSL][R]) {
-        float acc[R][EMAX];
+        // the FMAs go two at a time through v_pk_fma_f32 (two independent IEEE FMAs: the chains are unchanged): the two
+        // rows of the pair with one wg value (R = 2), or two experts with one x value (R = 1).  As scalar v_fmac_f32 they
+        // were ~1000 of the ~1750 VALU cycles a wave spends per row pair.
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        constexpr int NP = R * EMAX / 2;  // packed accumulators: [e] = rows (0, 1) when R == 2, [e / 2] = experts (e, e + 1) when R == 1
+        static_assert(R == 1 || R == 2, "rows per step");
+        static_assert(EMAX % 2 == 0, "experts are packed in pairs when R == 1");
+        f32x2_t acc2[NP];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int e = 0; e < EMAX; ++e) acc[r][e] = 0.f;
+        for (int k = 0; k < NP; ++k) acc2[k] = f32x2_t{0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NSL; ++i) {
             float xf[R][8];
 #pragma unroll
             for (int r = 0; r < R; ++r) unpack8_t<DT>(q[i][r], xf[r]);
+            float w[EMAX][8];
 #pragma unroll
             for (int e = 0; e < EMAX; ++e) {
                 const float4 wa = s_wg[((e * NSL + i) * 2 + 0) * 64 + lane];
                 const float4 wb = s_wg[((e * NSL + i) * 2 + 1) * 64 + lane];
-                const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[r][e] = fmaf(xf[r][j], w[j], acc[r][e]);
+                w[e][0] = wa.x; w[e][1] = wa.y; w[e][2] = wa.z; w[e][3] = wa.w;
+                w[e][4] = wb.x; w[e][5] = wb.y; w[e][6] = wb.z; w[e][7] = wb.w;
             }
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f32x2_t xv = R == 2 ? f32x2_t{xf[0][j], xf[R - 1][j]} : f32x2_t{xf[0][j], xf[0][j]};
+                    const f32x2_t wv = R == 2 ? f32x2_t{w[k][j], w[k][j]} : f32x2_t{w[(2 * k) % EMAX][j], w[(2 * k + 1) % EMAX][j]};
+                    acc2[k] = __builtin_elementwise_fma(xv, wv, acc2[k]);
+                }
+
             // wg is the same for every row pair, so the compiler keeps all of it in registers across the loop (E x M / 64
             // = 128 registers at E = 4, M = 2048, 160 at M = 2560): no LDS reads are left in the loop; LDS is how the
             // waves get wg without every one of them pulling it through L1 / L2.  That is also why the form stops at
@@ -289,7 +301,8 @@ __global__ __launch_bounds__(GATE_STREAM_THREADS) void gate_logits_stream_kernel
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int e = 0; e < EMAX; ++e) {
-                const float v = wave_sum(acc[r][e]);
+                const float a = R == 2 ? acc2[e][r] : acc2[e / 2][e & 1];
+                const float v = wave_sum(a);
                 if (lane == 0 && pr * R + r < S) logits[(size_t)(pr * R + r) * EMAX + e] = v;
             }
     };
